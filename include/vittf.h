@@ -1,0 +1,211 @@
+/* vittf.h -- C ABI of the MI355X-native vit-tf hot path (libvittf.so, gfx950 only).
+ *
+ * The reference (xeTaiz/vit-tf) has no FFI: its hot path is Python calling stock PyTorch ops.
+ * This header is the boundary a maintainer binds instead (ctypes stub in INTEGRATION.md): every
+ * entry point names the reference lines whose arithmetic it replaces.  Conventions:
+ *
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host]
+ *   - the caller owns all memory; nothing is allocated inside (workspace passed in, size from the
+ *     matching *_workspace_bytes query); no host synchronisation inside any call
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work of a call is
+ *     enqueued on it in order, so calls compose without further synchronisation
+ *   - return value: 0 (VITTF_OK) or a negative vittf_status; no exceptions cross the ABI
+ *   - "h16" = the 16-bit arithmetic type selected by vittf_dtype (bf16 or fp16); feature volumes
+ *     and K features are always IEEE fp16 like the reference's files (infer.py:134, 337-340)
+ *   - thread-compatible: no global mutable state
+ */
+#ifndef VITTF_H
+#define VITTF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITTF_ABI_VERSION 1
+
+typedef enum vittf_status {
+  VITTF_OK = 0,
+  VITTF_ERR_INVALID_ARG = -1,   /* bad shape / null pointer / unsupported configuration */
+  VITTF_ERR_WORKSPACE = -2,     /* workspace too small */
+  VITTF_ERR_LAUNCH = -3,        /* HIP launch error (hipGetLastError != hipSuccess) */
+  VITTF_ERR_NO_DEVICE = -4      /* no gfx950 device visible */
+} vittf_status;
+
+typedef enum vittf_dtype { VITTF_BF16 = 0, VITTF_FP16 = 1 } vittf_dtype;
+
+/* slice axis, naming of infer.py:138-152 ('z' slices along the last volume dim) */
+typedef enum vittf_axis { VITTF_AXIS_X = 0, VITTF_AXIS_Y = 1, VITTF_AXIS_Z = 2 } vittf_axis;
+
+typedef enum vittf_sample_mode { VITTF_SAMPLE_NEAREST = 0, VITTF_SAMPLE_TRILINEAR = 1 } vittf_sample_mode;
+
+int vittf_abi_version(void);
+const char* vittf_status_string(int status);
+/* number of visible gfx950 devices (<= 0: none).  Does not create a context on failure. */
+int vittf_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * ViT description.  Replaces the module tree of the upstream DINO VisionTransformer that the
+ * reference fetches with torch.hub (infer.py:42-43, 323).  Head dim must be 64 (all DINO ViTs),
+ * embed_dim a multiple of 128, patch 8 or 16.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vittf_vit_config {
+  int32_t embed_dim;   /* D: 384 (ViT-S) / 768 (ViT-B) */
+  int32_t depth;       /* L: 12 */
+  int32_t heads;       /* D / 64 */
+  int32_t patch;       /* P: 8 */
+  int32_t dtype;       /* vittf_dtype of the MFMA operands */
+  float   ln_eps;      /* 1e-6 */
+} vittf_vit_config;
+
+/* All weights live in HBM for the lifetime of the engine (about 43 MB for ViT-S).  Per-layer tensors
+ * are stacked along a leading L dimension.  "h16" matrices are row-major [out][in] exactly like the
+ * nn.Linear weights of the DINO state dict, converted once to the engine dtype. */
+typedef struct vittf_vit_weights {
+  const float* pe_w_t;   /* [P*P][D]  patch-embed conv folded to ONE input channel, transposed (k-major);
+                            folding of the 3 identical grey channels + ImageNet mean/std: infer.py:39-40,154-155 */
+  const float* pe_b;     /* [D]       folded bias */
+  const void*  qkv_w;    /* h16 [L][3D][D]   blocks.i.attn.qkv.weight */
+  const float* qkv_b;    /* [L][3D] */
+  const void*  proj_w;   /* h16 [L][D][D]    blocks.i.attn.proj.weight */
+  const float* proj_b;   /* [L][D] */
+  const void*  fc1_w;    /* h16 [L][4D][D]   blocks.i.mlp.fc1.weight */
+  const float* fc1_b;    /* [L][4D] */
+  const void*  fc2_w;    /* h16 [L][D][4D]   blocks.i.mlp.fc2.weight */
+  const float* fc2_b;    /* [L][D] */
+  const float* ln1_g;    /* [L][D] */
+  const float* ln1_b;    /* [L][D] */
+  const float* ln2_g;    /* [L][D] */
+  const float* ln2_b;    /* [L][D] */
+} vittf_vit_weights;
+
+/* Position embedding for ONE image size, already interpolated on the host in the upstream
+ * scale-factor/bicubic form: row 0 = cls_token + pos[0], rows 1.. = patch part. */
+typedef struct vittf_pos_embed {
+  const float* cls_plus_pos0;  /* [D] */
+  const float* patch_pos;      /* [f0*f1][D] */
+} vittf_pos_embed;
+
+/* Where the slices of one axis sit inside the resident fp32 volume (W, H, D), C-contiguous.
+ * Replaces make_4d(vol).permute(permute_in) (infer.py:138-142, 154) without materialising it. */
+typedef struct vittf_slice_view {
+  const float* vol;        /* fp32 volume in HBM */
+  int64_t stride_slice;    /* element strides of the (slice, row, col) view */
+  int64_t stride_row;
+  int64_t stride_col;
+  int32_t in_rows;         /* slice size in volume voxels */
+  int32_t in_cols;
+  int32_t out_rows;        /* network input size (im_sz of the axis, multiple of P), nearest-resized: */
+  int32_t out_cols;        /*   src = min(floor(dst * in/out), in-1), F.interpolate 'nearest' infer.py:177 */
+  const float* minmax;     /* [2] device: global min, max of the volume (norm_minmax infer.py:32-34) */
+} vittf_slice_view;
+
+/* min / max of n floats -> out[2] (device).  ws: >= vittf_minmax_workspace_bytes() bytes.
+ * Replaces t.min(), t.max() of norm_minmax (infer.py:33). */
+size_t vittf_minmax_workspace_bytes(void);
+int vittf_volume_minmax(const float* vol, int64_t n, float* out_minmax, void* ws, size_t ws_bytes, void* stream);
+
+/* Bytes of workspace for a forward over `batch` slices of `tokens` = f0*f1 + 1 tokens. */
+size_t vittf_vit_workspace_bytes(const vittf_vit_config* cfg, int32_t batch, int32_t tokens);
+
+/* The ViT leg of compute_qkv (infer.py:173-177 + the hooked K third, infer.py:133-135, 189-203):
+ * for slices [slice0, slice0 + batch) of `view`: normalise, nearest-resize, patch-embed, (L-1) full
+ * blocks, then ONLY LayerNorm1 + the K projection of block L; the K features of the patch tokens
+ * (CLS dropped, infer.py:202) are rounded to fp16 (infer.py:134) and written token-major:
+ *     k_out[(s - slice0) * f0*f1 + token][D]      token = row-major over the (rows/P, cols/P) grid
+ * qkv_part selects the third of the hooked qkv tensor: 0 = q, 1 = k (what infer.py's __main__ asks for,
+ * infer.py:326,331), 2 = v  (compute_qkv's return_keys, infer.py:195-209).
+ * [host] cfg, w, pos, view are host structs holding device pointers. */
+int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit_weights* w, const vittf_pos_embed* pos,
+                         const vittf_slice_view* view, int32_t slice0, int32_t batch, int32_t qkv_part,
+                         uint16_t* k_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Individual kernels, exported so that each one is parity-tested on its own (tests/).
+ * Row counts: activations are [rows][cols] row-major; `rows` need not be tile aligned.
+ * ---------------------------------------------------------------------------------------- */
+
+/* tokens[b][0] = cls+pos0 ; tokens[b][1+p] = patch_embed(slice slice0+b)[p] + pos[p]   -> fp32 [batch][tokens][D] */
+int vittf_patch_embed(const vittf_vit_config* cfg, const vittf_vit_weights* w, const vittf_pos_embed* pos,
+                      const vittf_slice_view* view, int32_t slice0, int32_t batch, float* tokens_out, void* stream);
+
+/* y = LayerNorm(x) * g + b, x fp32 [rows][D] -> y h16 [rows][D]  (nn.LayerNorm, biased variance) */
+int vittf_layernorm(const float* x, const float* g, const float* b, void* y, int64_t rows, int32_t d,
+                    float eps, int32_t dtype, void* stream);
+
+typedef enum vittf_epilogue {
+  VITTF_EPI_BIAS = 0,        /* out h16 [rows][n] = a.w^T + bias */
+  VITTF_EPI_BIAS_GELU = 1,   /* out h16 [rows][n] = gelu_erf(a.w^T + bias)        (Mlp.fc1 + nn.GELU) */
+  VITTF_EPI_BIAS_RESIDUAL = 2,/* out fp32 [rows][n] += a.w^T + bias                (x = x + proj/fc2(...)) */
+  VITTF_EPI_KFEAT = 3        /* out fp16: rows whose (row % tokens) == 0 (CLS) are dropped, the others are
+                                written densely: out[(row/tokens)*(tokens-1) + row%tokens - 1][n] */
+} vittf_epilogue;
+
+/* out = epilogue(a[rows][k] . w[n][k]^T + bias[n]);  a, w: h16; k % 64 == 0, n % 128 == 0.
+ * `tokens` is only used by VITTF_EPI_KFEAT. */
+int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
+               int32_t epilogue, int32_t tokens, int32_t dtype, void* stream);
+
+/* Multi-head self-attention over `batch` independent sequences of `tokens` rows.
+ * qkv h16 [batch*tokens][3D] with columns [q | k | v], heads of 64 concatenated inside each third
+ * (layout of Attention.qkv's output); out h16 [batch*tokens][D] = softmax(q k^T / 8) v per head. */
+int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Feature-volume epilogue (infer.py:201-203 permute_out, :329 AdaptiveAvgPool3d, :330-332 axis sum).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Average-pool the slice axis of the token-major K features of ONE axis and scatter them, feature-major,
+ * into a pooled slab:  for window i in [win0, win0 + nwin):
+ *     slices [floor(i*S/n_out), ceil((i+1)*S/n_out))  (adaptive rule), fp32 sum in slice order, / count,
+ *     rounded to fp16;  written to dst[d*dst_stride_d + (i - win0)*dst_stride_win + r*dst_stride_row + c*dst_stride_col]
+ * k_slices holds slices [k_slice0, k_slice0 + k_nslices) of the axis as [slice][f0][f1][D] fp16; every
+ * slice a requested window touches must be inside that range.  n_out == S gives the un-pooled layout. */
+int vittf_pool_slices(const uint16_t* k_slices, int32_t k_slice0, int32_t k_nslices, int32_t total_slices,
+                      int32_t n_out, int32_t win0, int32_t nwin, int32_t f0, int32_t f1, int32_t d,
+                      uint16_t* dst, int64_t dst_stride_d, int64_t dst_stride_win, int64_t dst_stride_row,
+                      int64_t dst_stride_col, void* stream);
+
+/* out = fp16(fp16(z + y) + x) element-wise: the reference's running fp16 sum in z, y, x order
+ * (infer.py:330-332).  Inputs are the per-axis pooled volumes as gathered from `nranks` ranks:
+ * axis a is stored [nranks][D][...] where each rank block holds `chunk[a]` windows of the axis' slice
+ * dimension (slab layout written by vittf_pool_slices); out is (D, n0, n1, n2) fp16, C-contiguous. */
+int vittf_assemble_sum(const uint16_t* gz, const uint16_t* gy, const uint16_t* gx, int32_t nranks,
+                       const int32_t chunk[3], int32_t d, int32_t n0, int32_t n1, int32_t n2, uint16_t* out,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Similarity query (predict_ntf.py:52-72, 95-100) and label assignment (predict_ntf.py:203-215).
+ * ---------------------------------------------------------------------------------------- */
+
+/* F.grid_sample of the feature volume (infer.py:48-72): feat fp16 or fp32 (F, n0, n1, n2); rel fp32 [A][3]
+ * relative coordinates in [-1, 1] in VOLUME dim order (the flip to grid_sample's x,y,z order of infer.py:67
+ * happens inside); align_corners=False, zero padding; mode nearest or trilinear ('bilinear').  out fp32 [A][F]. */
+int vittf_sample_features(const void* feat, int32_t feat_is_fp16, int32_t f, int32_t n0, int32_t n1, int32_t n2,
+                          const float* rel, int32_t a, int32_t mode, float* out, void* stream);
+
+size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox);
+
+/* Fused similarity: for every voxel v and class c with annotations [class_start[c], class_start[c+1]):
+ *     dot[a] = sum_f feat[f][v] * qf[a][f]                       (einsum predict_ntf.py:65)
+ *     sim_c  = mean_a( dot[a] >= 0.25 ? dot[a]^2.5 : 0 )         (predict_ntf.py:71-72)
+ *     (big_a_mean != 0: the single-class A > 1024 variant, mean of raw dots first, predict_ntf.py:62-63)
+ *     u8     = trunc(255 / (0.99 * max_v sim_c) * sim_c) mod 256 (predict_ntf.py:98-99, x86 wrap-around)
+ * then nearest-resized to (o0, o1, o2) (predict_ntf.py:100).  feat fp16 (F, n0, n1, n2) F-major;
+ * qf fp32 [A][F]; class_start int32 [classes + 1] on the HOST; out uint8 [classes][o0][o1][o2]. */
+int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
+                     const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
+                     int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws, size_t ws_bytes, void* stream);
+
+/* pred = 0; best = 0; for i: mask = sims[i] > thr[i] && sims[i] > best; pred[mask] = i+1; best[mask] = sims[i]
+ * sims uint8 [classes][n]; thr int32 [classes] on the HOST (= int(t*255), predict_ntf.py:212); labels uint8 [n]. */
+int vittf_assign_labels(const uint8_t* sims, int32_t classes, int64_t n, const int32_t* thr_host, uint8_t* labels,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITTF_H */

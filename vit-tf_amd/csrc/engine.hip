@@ -1,0 +1,123 @@
+// Orchestration of one batch of slices through the ViT: the C-ABI entry the Python host calls once per batch.
+//
+// Replaces the body of the reference's hot loop `model(F.interpolate(im_in[batch], ...).to(dev))` plus the
+// forward hook on blocks[-1].attn.qkv (infer.py:133-135, 173-177): patch embed, (L-1) full pre-norm blocks and
+// then only LayerNorm1 + the K third of the last block's qkv projection -- the rest of block L and the final
+// norm never influence the hooked tensor, so they are not executed.
+//
+// Workspace layout for `batch` slices of N tokens (rows = batch * N, padded to the GEMM tile):
+//   X    fp32 [rows][D]      residual stream
+//   H    h16  [rows][D]      LayerNorm output / attention output (MFMA operand)
+//   QKV  h16  [rows][3D]     attention input; QKV|O is re-used as the [rows][4D] MLP hidden buffer
+//   O    h16  [rows][D]
+// Everything is enqueued on the caller's stream; nothing synchronises with the host.
+#include "vittf_common.h"
+
+namespace {
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct WsLayout {
+  size_t x, h, qkv, o, total;
+};
+
+WsLayout ws_layout(int d, int64_t rows) {
+  const int64_t rp = (rows + 127) / 128 * 128;
+  WsLayout l;
+  size_t off = 0;
+  l.x = off;   off += align256((size_t)rp * d * 4);
+  l.h = off;   off += align256((size_t)rp * d * 2);
+  l.qkv = off; off += (size_t)rp * 3 * d * 2;   // QKV and O contiguous: together the [rows][4D] hidden buffer
+  l.o = off;   off += align256((size_t)rp * d * 2);
+  l.total = off;
+  return l;
+}
+
+bool config_ok(const vittf_vit_config* c) {
+  return c && c->embed_dim > 0 && c->embed_dim % 128 == 0 && c->embed_dim <= 1024 && c->depth >= 1 &&
+         c->heads * 64 == c->embed_dim && (c->patch == 8 || c->patch == 16) &&
+         (c->dtype == VITTF_BF16 || c->dtype == VITTF_FP16) && c->ln_eps > 0.f;
+}
+}  // namespace
+
+extern "C" int vittf_abi_version(void) { return VITTF_ABI_VERSION; }
+
+extern "C" const char* vittf_status_string(int status) {
+  switch (status) {
+    case VITTF_OK: return "ok";
+    case VITTF_ERR_INVALID_ARG: return "invalid argument";
+    case VITTF_ERR_WORKSPACE: return "workspace too small";
+    case VITTF_ERR_LAUNCH: return "HIP launch error";
+    case VITTF_ERR_NO_DEVICE: return "no gfx950 device";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int vittf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && __builtin_strstr(p.gcnArchName, "gfx950")) ++ok;
+  }
+  return ok;
+}
+
+extern "C" size_t vittf_vit_workspace_bytes(const vittf_vit_config* cfg, int32_t batch, int32_t tokens) {
+  if (!config_ok(cfg) || batch <= 0 || tokens <= 1) return 0;
+  return ws_layout(cfg->embed_dim, (int64_t)batch * tokens).total;
+}
+
+extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit_weights* w, const vittf_pos_embed* pos,
+                                    const vittf_slice_view* view, int32_t slice0, int32_t batch, int32_t qkv_part,
+                                    uint16_t* k_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!config_ok(cfg) || !w || !pos || !view || !k_out || !ws || batch <= 0 || slice0 < 0) return VITTF_ERR_INVALID_ARG;
+  if (qkv_part < 0 || qkv_part > 2) return VITTF_ERR_INVALID_ARG;
+  if (!w->qkv_w || !w->qkv_b || !w->proj_w || !w->proj_b || !w->fc1_w || !w->fc1_b || !w->fc2_w || !w->fc2_b ||
+      !w->ln1_g || !w->ln1_b || !w->ln2_g || !w->ln2_b)
+    return VITTF_ERR_INVALID_ARG;
+  const int d = cfg->embed_dim, p = cfg->patch, L = cfg->depth, dt = cfg->dtype;
+  if (view->out_rows % p || view->out_cols % p) return VITTF_ERR_INVALID_ARG;
+  const int tokens = (view->out_rows / p) * (view->out_cols / p) + 1;
+  const int64_t rows = (int64_t)batch * tokens;
+  const WsLayout lay = ws_layout(d, rows);
+  if (ws_bytes < lay.total) return VITTF_ERR_WORKSPACE;
+  if (((uintptr_t)ws & 255) != 0) return VITTF_ERR_INVALID_ARG;
+  char* base = (char*)ws;
+  float* X = (float*)(base + lay.x);
+  void* H = base + lay.h;
+  void* QKV = base + lay.qkv;
+  void* O = base + lay.o;
+  void* G = QKV;  // [rows][4D] hidden, aliases QKV|O (both dead while the MLP runs)
+
+  int rc = vittf_patch_embed(cfg, w, pos, view, slice0, batch, X, stream);
+  if (rc) return rc;
+  const size_t esz = 2;
+  for (int l = 0; l < L; ++l) {
+    const char* qkv_w = (const char*)w->qkv_w + (size_t)l * 3 * d * d * esz;
+    rc = vittf_layernorm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
+    if (rc) return rc;
+    if (l == L - 1) {
+      // hooked tensor, one third only: rows [part*D, (part+1)*D) of qkv.weight / qkv.bias  (infer.py:189-201)
+      return vittf_gemm(H, qkv_w + (size_t)qkv_part * d * d * esz, w->qkv_b + (size_t)l * 3 * d + (size_t)qkv_part * d,
+                        k_out, rows, d, d,
+                        VITTF_EPI_KFEAT, tokens, dt, stream);
+    }
+    rc = vittf_gemm(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, VITTF_EPI_BIAS, 0, dt, stream);
+    if (rc) return rc;
+    rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, stream);
+    if (rc) return rc;
+    rc = vittf_gemm(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d, d,
+                    VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream);
+    if (rc) return rc;
+    rc = vittf_layernorm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
+    if (rc) return rc;
+    rc = vittf_gemm(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows,
+                    4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream);
+    if (rc) return rc;
+    rc = vittf_gemm(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
+                    4 * d, VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream);
+    if (rc) return rc;
+  }
+  return VITTF_OK;
+}

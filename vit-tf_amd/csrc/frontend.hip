@@ -1,0 +1,159 @@
+// Front end of the slice loop: global min/max of the volume, and the fused
+//   slice gather -> min-max normalise -> nearest resize -> patch-embed conv -> + CLS / position embedding.
+//
+// Replaces, without materialising the (S, 3, h, w) fp32 tensor the reference builds:
+//   norm_minmax (infer.py:32-34), the 3-channel expand + ImageNet normalize (infer.py:154-155),
+//   F.interpolate(..., mode='nearest') (infer.py:177) and PatchEmbed + prepare_tokens of the upstream ViT.
+// The three input channels are the same grey value, so the conv is folded on the host to ONE input channel
+// (P*P taps) plus a bias; the arithmetic here is exact fp32 (VALU FMAs) -- the front end is < 0.1 % of the
+// path's FLOPs and the precision of the first layer is worth more than its speed.
+#include "vittf_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- min / max
+constexpr int MM_BLOCKS = 1024;
+
+__device__ __forceinline__ void wave_minmax(float& lo, float& hi) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, off));
+    hi = fmaxf(hi, __shfl_xor(hi, off));
+  }
+}
+
+__device__ __forceinline__ void block_minmax(float& lo, float& hi) {
+  __shared__ float s_lo[4], s_hi[4];
+  wave_minmax(lo, hi);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+  __syncthreads();
+  lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+  hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+}
+
+__global__ __launch_bounds__(256) void minmax_partial(const float* __restrict__ v, int64_t n, float* __restrict__ part) {
+  float lo = INFINITY, hi = -INFINITY;
+  const int64_t n4 = n >> 2;
+  const float4* v4 = reinterpret_cast<const float4*>(v);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 x = v4[i];
+    lo = fminf(fminf(lo, x.x), fminf(fminf(x.y, x.z), x.w));
+    hi = fmaxf(fmaxf(hi, x.x), fmaxf(fmaxf(x.y, x.z), x.w));
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) { lo = fminf(lo, v[i]); hi = fmaxf(hi, v[i]); }
+  block_minmax(lo, hi);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = lo; part[2 * blockIdx.x + 1] = hi; }
+}
+
+__global__ __launch_bounds__(256) void minmax_final(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
+  float lo = INFINITY, hi = -INFINITY;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { lo = fminf(lo, part[2 * i]); hi = fmaxf(hi, part[2 * i + 1]); }
+  block_minmax(lo, hi);
+  if (threadIdx.x == 0) { out[0] = lo; out[1] = hi; }
+}
+
+// ---------------------------------------------------------------- patch embed
+// One workgroup = TP patches of one slice x all D output features.
+//   phase 1: gather the TP x P*P normalised grey values into LDS (fp32)
+//   phase 2: thread d (and d + 256, ...) accumulates its feature for every patch; the folded weights are
+//            k-major [P*P][D] so the per-thread weight reads are coalesced, the pixel reads are LDS broadcasts
+constexpr int TP = 32;
+
+template <int P>
+__global__ __launch_bounds__(256) void patch_embed_kernel(vittf_slice_view view, int slice0, const float* __restrict__ w_t,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ cls_pos0,
+                                                          const float* __restrict__ patch_pos, float* __restrict__ tokens_out,
+                                                          int d, int f0, int f1) {
+  constexpr int PP = P * P;
+  __shared__ float px[TP][PP + 1];
+  const int npatch = f0 * f1;
+  const int tokens = npatch + 1;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * TP;
+  const float lo = view.minmax[0], hi = view.minmax[1];
+  const float range = hi - lo;
+  // F.interpolate(mode='nearest'): src = min(floor(dst * (in / out)), in - 1), scale in fp32
+  const float sr = (float)view.in_rows / (float)view.out_rows;
+  const float sc = (float)view.in_cols / (float)view.out_cols;
+  const float* slice = view.vol + (int64_t)(slice0 + b) * view.stride_slice;
+
+  for (int e = threadIdx.x; e < TP * PP; e += 256) {
+    const int pl = e / PP, k = e - pl * PP;
+    const int p = p0 + pl;
+    float v = 0.f;
+    if (p < npatch) {
+      const int py = p / f1, pxx = p - py * f1;
+      const int iy = py * P + k / P, ix = pxx * P + k % P;
+      int ry = (int)floorf((float)iy * sr);
+      int cx = (int)floorf((float)ix * sc);
+      ry = ry < view.in_rows - 1 ? ry : view.in_rows - 1;
+      cx = cx < view.in_cols - 1 ? cx : view.in_cols - 1;
+      const float raw = slice[(int64_t)ry * view.stride_row + (int64_t)cx * view.stride_col];
+      v = (raw - lo) / range;
+    }
+    px[pl][k] = v;
+  }
+  __syncthreads();
+
+  float* out_b = tokens_out + (int64_t)b * tokens * d;
+  for (int dd = threadIdx.x; dd < d; dd += 256) {
+    float acc[TP];
+#pragma unroll
+    for (int i = 0; i < TP; ++i) acc[i] = 0.f;
+    for (int k = 0; k < PP; ++k) {
+      const float wv = w_t[(int64_t)k * d + dd];
+#pragma unroll
+      for (int i = 0; i < TP; ++i) acc[i] = fmaf(px[i][k], wv, acc[i]);
+    }
+    const float bv = bias[dd];
+#pragma unroll
+    for (int i = 0; i < TP; ++i) {
+      const int p = p0 + i;
+      if (p < npatch) out_b[(int64_t)(1 + p) * d + dd] = acc[i] + bv + patch_pos[(int64_t)p * d + dd];
+    }
+    if (blockIdx.x == 0) out_b[dd] = cls_pos0[dd];
+  }
+}
+
+}  // namespace
+
+extern "C" size_t vittf_minmax_workspace_bytes(void) { return 2 * MM_BLOCKS * sizeof(float); }
+
+extern "C" int vittf_volume_minmax(const float* vol, int64_t n, float* out_minmax, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (!vol || !out_minmax || !ws || n <= 0) return VITTF_ERR_INVALID_ARG;
+  if (ws_bytes < vittf_minmax_workspace_bytes()) return VITTF_ERR_WORKSPACE;
+  if (((uintptr_t)vol & 15) != 0) return VITTF_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t want = (n / 4 + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > MM_BLOCKS ? MM_BLOCKS : want));
+  hipLaunchKernelGGL(minmax_partial, dim3(blocks), dim3(256), 0, st, vol, n, (float*)ws);
+  hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, out_minmax);
+  return vittf_check_launch();
+}
+
+extern "C" int vittf_patch_embed(const vittf_vit_config* cfg, const vittf_vit_weights* w, const vittf_pos_embed* pos,
+                                 const vittf_slice_view* view, int32_t slice0, int32_t batch, float* tokens_out,
+                                 void* stream) {
+  if (!cfg || !w || !pos || !view || !tokens_out || batch <= 0 || slice0 < 0) return VITTF_ERR_INVALID_ARG;
+  if (!w->pe_w_t || !w->pe_b || !pos->cls_plus_pos0 || !pos->patch_pos || !view->vol || !view->minmax)
+    return VITTF_ERR_INVALID_ARG;
+  const int p = cfg->patch;
+  if ((p != 8 && p != 16) || view->out_rows % p || view->out_cols % p || view->out_rows <= 0 || view->out_cols <= 0)
+    return VITTF_ERR_INVALID_ARG;
+  if (view->in_rows <= 0 || view->in_cols <= 0 || batch > 65535) return VITTF_ERR_INVALID_ARG;
+  const int f0 = view->out_rows / p, f1 = view->out_cols / p;
+  const int nblk = (f0 * f1 + TP - 1) / TP;
+  hipStream_t st = (hipStream_t)stream;
+  if (p == 8) {
+    hipLaunchKernelGGL((patch_embed_kernel<8>), dim3(nblk, batch), dim3(256), 0, st, *view, slice0, w->pe_w_t, w->pe_b,
+                       pos->cls_plus_pos0, pos->patch_pos, tokens_out, cfg->embed_dim, f0, f1);
+  } else {
+    hipLaunchKernelGGL((patch_embed_kernel<16>), dim3(nblk, batch), dim3(256), 0, st, *view, slice0, w->pe_w_t, w->pe_b,
+                       pos->cls_plus_pos0, pos->patch_pos, tokens_out, cfg->embed_dim, f0, f1);
+  }
+  return vittf_check_launch();
+}

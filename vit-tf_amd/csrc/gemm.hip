@@ -1,0 +1,202 @@
+// MFMA GEMM for the ViT linears:  out = epilogue(A[rows][K] . W[N][K]^T + bias[N])
+//
+// Replaces nn.Linear (attn.qkv, attn.proj, mlp.fc1 + GELU, mlp.fc2) of the upstream DINO blocks that the
+// reference runs through torch (infer.py:177 -> model(...)); the fused epilogues replace the separate
+// bias / GELU / residual-add passes.
+//
+// Shape of the machine mapping (gfx950):
+//   * 128 x 128 output tile per 256-thread workgroup, 4 waves as 2 (m) x 2 (n), each wave 64 x 64
+//   * K step 64; A and W tiles are [128][64 x 16 bit] images (16 KB each) filled by global_load_lds_dwordx4
+//     (no VGPR staging); the XOR swizzle of tile_off() is applied on the per-lane SOURCE address because the
+//     LDS destination of an LDS-DMA is lane-linear; two buffers, the load of step t+1 overlaps the MFMAs of t
+//   * v_mfma_f32_32x32x16 with W as the A operand and the activations as the B operand, i.e. the wave
+//     computes C^T: a lane then owns ONE activation row and 4 consecutive output columns per register quad,
+//     so bias loads are float4 and stores are 8 B (16-bit out) or 16 B (fp32 residual) per lane
+//   * workgroups are remapped so that consecutive tiles (which share the A panel) run on one XCD's L2
+#include "vittf_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KB
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  // exact-erf GELU 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = 1.0f - p * __expf(-z * z);
+  const float erfv = x < 0.f ? -e : e;
+  return 0.5f * x * (1.0f + erfv);
+}
+
+// issue the LDS-DMA of one [128][64] operand tile: 1024 16-byte chunks, 4 per thread
+template <typename T>
+__device__ __forceinline__ void stage_tile(const T* __restrict__ src, int64_t ld, int64_t row0, int64_t row_max,
+                                           int k0, char* lds_tile, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 256 + tid;
+    int r, c;
+    tile_pos(q, r, c);
+    int64_t row = row0 + r;
+    row = row < row_max ? row : row_max;  // clamp: rows past the end re-read the last row, never stored
+    const T* g = src + row * ld + k0 + c * 8;
+    // wave-uniform LDS base; the hardware adds lane * 16
+    char* dst = lds_tile + ((i * 256 + (tid & ~63)) << 4);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(dst), 16, 0, 0);
+  }
+}
+
+template <int DT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const unsigned short* __restrict__ A,
+                                                      const unsigned short* __restrict__ W,
+                                                      const float* __restrict__ bias, void* __restrict__ out,
+                                                      int64_t rows, int n, int k, int tokens, int n_tiles,
+                                                      int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | W tile]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int tile = xcd_remap(blockIdx.x, total_tiles);
+  const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
+  const int64_t m0 = (int64_t)mt * BM;
+  const int n0 = nt * BN;
+
+  f32x16_t acc[2][2];  // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = k / BK;
+  stage_tile(A, k, m0, rows - 1, 0, smem, tid);
+  stage_tile(W, k, n0, n - 1, 0, smem + TILE_BYTES, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    char* cur = smem + (t & 1) * 2 * TILE_BYTES;
+    if (t + 1 < nk) {
+      char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+      stage_tile(A, k, m0, rows - 1, (t + 1) * BK, nxt, tid);
+      stage_tile(W, k, n0, n - 1, (t + 1) * BK, nxt + TILE_BYTES, tid);
+    }
+    const char* a_t = cur;
+    const char* w_t = cur + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = 2 * s + h;
+      s16x8_t af[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const s16x8_t*>(a_t + tile_off(wm * 64 + i * 32 + l31, c));
+        wf[i] = *reinterpret_cast<const s16x8_t*>(w_t + tile_off(wn * 64 + i * 32 + l31, c));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = mfma32<DT>(wf[ni], af[mi], acc[ni][mi]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns activation row m (per mi) and columns nb + 8g + 4h + {0..3} ----
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int64_t m = m0 + wm * 64 + mi * 32 + l31;
+    if (m >= rows) continue;
+    int64_t orow = m;
+    if constexpr (EPI == VITTF_EPI_KFEAT) {
+      const int64_t b = m / tokens;
+      const int tok = (int)(m - b * tokens);
+      if (tok == 0) continue;  // CLS row dropped (infer.py:202 k[:, 1:])
+      orow = b * (tokens - 1) + tok - 1;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = n0 + wn * 64 + ni * 32 + 8 * g + 4 * h;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+        float v0 = acc[ni][mi][4 * g + 0] + bv.x;
+        float v1 = acc[ni][mi][4 * g + 1] + bv.y;
+        float v2 = acc[ni][mi][4 * g + 2] + bv.z;
+        float v3 = acc[ni][mi][4 * g + 3] + bv.w;
+        if constexpr (EPI == VITTF_EPI_BIAS_RESIDUAL) {
+          float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + orow * n + col);
+          float4 x = *p;
+          x.x += v0; x.y += v1; x.z += v2; x.w += v3;
+          *p = x;
+        } else {
+          if constexpr (EPI == VITTF_EPI_BIAS_GELU) {
+            v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+          }
+          uint2 pk;
+          if constexpr (EPI == VITTF_EPI_KFEAT) {
+            pk.x = pack2_h16<VITTF_FP16>(v0, v1);
+            pk.y = pack2_h16<VITTF_FP16>(v2, v3);
+          } else {
+            pk.x = pack2_h16<DT>(v0, v1);
+            pk.y = pack2_h16<DT>(v2, v3);
+          }
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + orow * n + col) = pk;
+        }
+      }
+    }
+  }
+}
+
+template <int DT>
+int launch_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int n, int k, int epi,
+                int tokens, hipStream_t st) {
+  const int m_tiles = (int)((rows + BM - 1) / BM), n_tiles = n / BN;
+  const int total = m_tiles * n_tiles;
+  const size_t lds = 4 * TILE_BYTES;
+  const unsigned short* A = (const unsigned short*)a;
+  const unsigned short* Wp = (const unsigned short*)w;
+#define VITTF_GEMM_CASE(E)                                                                                   \
+  case E: {                                                                                                  \
+    static bool attr_set = false;                                                                            \
+    if (!attr_set) {                                                                                         \
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                   \
+      attr_set = true;                                                                                       \
+    }                                                                                                        \
+    hipLaunchKernelGGL((gemm_kernel<DT, E>), dim3(total), dim3(256), lds, st, A, Wp, bias, out, rows, n, k,  \
+                       tokens, n_tiles, total);                                                              \
+    break;                                                                                                   \
+  }
+  switch (epi) {
+    VITTF_GEMM_CASE(VITTF_EPI_BIAS)
+    VITTF_GEMM_CASE(VITTF_EPI_BIAS_GELU)
+    VITTF_GEMM_CASE(VITTF_EPI_BIAS_RESIDUAL)
+    VITTF_GEMM_CASE(VITTF_EPI_KFEAT)
+    default: return VITTF_ERR_INVALID_ARG;
+  }
+#undef VITTF_GEMM_CASE
+  return vittf_check_launch();
+}
+
+}  // namespace
+
+extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n,
+                          int32_t k, int32_t epilogue, int32_t tokens, int32_t dtype, void* stream) {
+  if (!a || !w || !bias || !out || rows <= 0 || n <= 0 || k <= 0) return VITTF_ERR_INVALID_ARG;
+  if (n % BN != 0 || k % BK != 0) return VITTF_ERR_INVALID_ARG;
+  if (epilogue == VITTF_EPI_KFEAT && tokens < 2) return VITTF_ERR_INVALID_ARG;
+  if (rows / BM + 1 > (1 << 20)) return VITTF_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VITTF_BF16) return launch_gemm<VITTF_BF16>(a, w, bias, out, rows, n, k, epilogue, tokens, st);
+  if (dtype == VITTF_FP16) return launch_gemm<VITTF_FP16>(a, w, bias, out, rows, n, k, epilogue, tokens, st);
+  return VITTF_ERR_INVALID_ARG;
+}

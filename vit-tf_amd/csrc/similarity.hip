@@ -1,0 +1,299 @@
+// Similarity query over the feature volume: query sampling, fused dot-product / threshold / power / class mean,
+// global-max quantisation to uint8 with nearest resize, and label assignment.
+//
+// Replaces sample_features3d (infer.py:48-72), the einsum + where/pow/mean + quantise + F.interpolate chain of
+// compute_similarities (predict_ntf.py:56-72, 95-100) and the running-max labels (predict_ntf.py:203-215).
+//
+// The feature volume is F-major fp16: voxel index contiguous, stride Nvox between features.  For the interactive
+// regime (A <= a few dozen) the dot products are HBM-bound: every voxel's 2*F bytes are read ONCE per chunk of 16
+// annotations, coalesced 8 B per lane, and the reference's A*4 B/voxel intermediate never exists.  Query vectors
+// are wave-uniform (scalar loads of a transposed [F][16] copy); all arithmetic is fp32 like the reference CPU path.
+#include "vittf_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- query sampling (grid_sample 3-D)
+template <bool HALF>
+__device__ __forceinline__ float feat_at(const void* feat, int64_t idx) {
+  if constexpr (HALF) return f16bits_to_f32(reinterpret_cast<const unsigned short*>(feat)[idx]);
+  else return reinterpret_cast<const float*>(feat)[idx];
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(256) void sample_kernel(const void* __restrict__ feat, int f, int n0, int n1, int n2,
+                                                     const float* __restrict__ rel, int na, int mode,
+                                                     float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)na * f) return;
+  const int a = (int)(e / f), ff = (int)(e - (int64_t)a * f);
+  // rel is in volume dim order; grid_sample's x <-> last volume dim (the flip of infer.py:67)
+  const float r0 = rel[3 * a + 0], r1 = rel[3 * a + 1], r2 = rel[3 * a + 2];
+  // unnormalise, align_corners=False: ((g + 1) * size - 1) / 2
+  const float iz = ((r0 + 1.f) * (float)n0 - 1.f) / 2.f;   // along n0 ("depth" of grid_sample)
+  const float iy = ((r1 + 1.f) * (float)n1 - 1.f) / 2.f;
+  const float ix = ((r2 + 1.f) * (float)n2 - 1.f) / 2.f;   // along n2 (contiguous)
+  const int64_t plane = (int64_t)n1 * n2;
+  const int64_t fbase = (int64_t)ff * n0 * plane;
+  float res = 0.f;
+  if (mode == VITTF_SAMPLE_NEAREST) {
+    const int x = (int)rintf(ix), y = (int)rintf(iy), z = (int)rintf(iz);
+    if (x >= 0 && x < n2 && y >= 0 && y < n1 && z >= 0 && z < n0)
+      res = feat_at<HALF>(feat, fbase + z * plane + (int64_t)y * n2 + x);
+  } else {
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz;
+    const float wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy, wz0 = (fz + 1.f) - iz;
+    // corner order and weight products of the CPU grid_sampler_3d: tnw, tne, tsw, tse, bnw, bne, bsw, bse
+#pragma unroll
+    for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          const int x = x0 + cx, y = y0 + cy, z = z0 + cz;
+          const float wgt = (cx ? wx1 : wx0) * (cy ? wy1 : wy0) * (cz ? wz1 : wz0);
+          if (x >= 0 && x < n2 && y >= 0 && y < n1 && z >= 0 && z < n0)
+            res = __fadd_rn(res, __fmul_rn(feat_at<HALF>(feat, fbase + z * plane + (int64_t)y * n2 + x), wgt));  // unfused, like the CPU op
+        }
+  }
+  out[e] = res;
+}
+
+// ---------------------------------------------------------------- similarity
+constexpr int ACH = 16;   // annotations per pass over the volume
+constexpr int VPT = 4;    // voxels per thread (8-byte loads)
+constexpr int MAXC = 8;   // classes handled by one pass (more classes: several launches)
+
+struct SimChunk {
+  int n_ann;          // annotations in this chunk (<= ACH)
+  int cls[ACH];       // class of each annotation, relative to c0
+  int c0, nc;         // classes [c0, c0 + nc) are touched by this chunk
+  int first[MAXC];    // chunk holds the first annotations of that class -> overwrite instead of accumulate
+  int last[MAXC];     // chunk holds the last annotations of that class  -> finalise (mean, max)
+  float count[MAXC];    // annotations of that class (fp32, exact)
+};
+
+// qf_t: [F][ACH] fp32 transposed query block for this chunk (zero padded)
+__global__ __launch_bounds__(256) void transpose_queries(const float* __restrict__ qf, int f, int a0, int n_ann,
+                                                         float* __restrict__ qf_t) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= f * ACH) return;
+  const int ff = e / ACH, a = e - ff * ACH;
+  qf_t[e] = a < n_ann ? qf[(int64_t)(a0 + a) * f + ff] : 0.f;
+}
+
+__device__ __forceinline__ float thresh_pow(float s) {
+  // where(s >= 0.25, s, 0) ** 2.5   (predict_ntf.py:71)
+  return s >= 0.25f ? s * s * sqrtf(s) : 0.f;
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(256) void sim_accumulate(const unsigned short* __restrict__ feat, int f, int64_t nvox,
+                                                      const float* __restrict__ qf_t, SimChunk ch,
+                                                      float* __restrict__ sim, unsigned* __restrict__ maxbits) {
+  const int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VPT;
+  float acc[ACH][VPT];
+#pragma unroll
+  for (int a = 0; a < ACH; ++a)
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) acc[a][j] = 0.f;
+  const bool full = v0 + VPT <= nvox;
+  if (v0 < nvox) {
+    const bool vec = full && ((nvox & 3) == 0);
+    for (int ff = 0; ff < f; ++ff) {
+      float x[VPT];
+      const unsigned short* p = feat + (int64_t)ff * nvox + v0;
+      if (vec) {
+        const uint2 raw = *reinterpret_cast<const uint2*>(p);
+        x[0] = f16bits_to_f32((unsigned short)(raw.x & 0xffff)); x[1] = f16bits_to_f32((unsigned short)(raw.x >> 16));
+        x[2] = f16bits_to_f32((unsigned short)(raw.y & 0xffff)); x[3] = f16bits_to_f32((unsigned short)(raw.y >> 16));
+      } else {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) x[j] = (v0 + j < nvox) ? f16bits_to_f32(p[j]) : 0.f;
+      }
+      const float* q = qf_t + ff * ACH;   // wave-uniform -> scalar loads
+#pragma unroll
+      for (int a = 0; a < ACH; ++a) {
+        const float qa = q[a];
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) acc[a][j] = fmaf(x[j], qa, acc[a][j]);
+      }
+    }
+  }
+  // per-class reduction over the chunk's annotations
+  float blockmax[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    blockmax[c] = 0.f;
+    if (c < ch.nc) {
+      float cs[VPT];
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) cs[j] = 0.f;
+#pragma unroll
+      for (int a = 0; a < ACH; ++a)
+        if (a < ch.n_ann && ch.cls[a] == c) {
+#pragma unroll
+          for (int j = 0; j < VPT; ++j) cs[j] += BIG ? acc[a][j] : thresh_pow(acc[a][j]);
+        }
+      float* dst = sim + (int64_t)(ch.c0 + c) * nvox + v0;
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        if (v0 + j < nvox) {
+          float t = cs[j];
+          if (!ch.first[c]) t += dst[j];
+          if (ch.last[c]) {
+            t = t / ch.count[c];                // mean = sum / count (predict_ntf.py:72 / :63), true division
+            if (BIG) t = thresh_pow(t);
+            blockmax[c] = fmaxf(blockmax[c], t);
+          }
+          dst[j] = t;
+        }
+      }
+    }
+  }
+  // sims are >= 0, so the uint bit pattern orders like the float: one atomicMax per wave per finished class
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    if (c < ch.nc && ch.last[c]) {
+      float m = blockmax[c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxbits + ch.c0 + c, __float_as_uint(m));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sim_quantize(const float* __restrict__ sim, const unsigned* __restrict__ maxbits,
+                                                    int classes, int n0, int n1, int n2, int o0, int o1, int o2,
+                                                    unsigned char* __restrict__ out) {
+  const int64_t per = (int64_t)o0 * o1 * o2;
+  const int64_t total = per * classes;
+  const float s0 = (float)n0 / (float)o0, s1 = (float)n1 / (float)o1, s2 = (float)n2 / (float)o2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e / per);
+    int64_t t = e - (int64_t)c * per;
+    const int z = (int)(t % o2); t /= o2;
+    const int y = (int)(t % o1);
+    const int x = (int)(t / o1);
+    int sx = (int)floorf((float)x * s0), sy = (int)floorf((float)y * s1), sz = (int)floorf((float)z * s2);
+    sx = sx < n0 - 1 ? sx : n0 - 1; sy = sy < n1 - 1 ? sy : n1 - 1; sz = sz < n2 - 1 ? sz : n2 - 1;
+    const float v = sim[(int64_t)c * n0 * n1 * n2 + ((int64_t)sx * n1 + sy) * n2 + sz];
+    const float quant = 0.99f * __uint_as_float(maxbits[c]);     // 0.99 * sim.max()      predict_ntf.py:98
+    const float q = (255.0f / quant) * v;                        // 255 / quant * sim     predict_ntf.py:99
+    // .to(torch.uint8) on x86: truncate toward zero, keep the low byte (257 -> 1); NaN (max == 0) -> 0
+    const int qi = (q == q) ? (int)q : 0;
+    out[e] = (unsigned char)(qi & 255);
+  }
+}
+
+struct LabelArgs { int classes; int thr[16]; };
+
+__global__ __launch_bounds__(256) void labels_kernel(const unsigned char* __restrict__ sims, int64_t n, LabelArgs a,
+                                                     unsigned char* __restrict__ labels) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    int pred = 0, best = 0;
+    for (int c = 0; c < a.classes; ++c) {
+      const int s = sims[(int64_t)c * n + e];
+      if (s > a.thr[c] && s > best) { pred = c + 1; best = s; }
+    }
+    labels[e] = (unsigned char)pred;
+  }
+}
+
+}  // namespace
+
+extern "C" int vittf_sample_features(const void* feat, int32_t feat_is_fp16, int32_t f, int32_t n0, int32_t n1, int32_t n2,
+                                     const float* rel, int32_t a, int32_t mode, float* out, void* stream) {
+  if (!feat || !rel || !out || f <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0 || a <= 0) return VITTF_ERR_INVALID_ARG;
+  if (mode != VITTF_SAMPLE_NEAREST && mode != VITTF_SAMPLE_TRILINEAR) return VITTF_ERR_INVALID_ARG;
+  const int64_t total = (int64_t)a * f;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (feat_is_fp16)
+    hipLaunchKernelGGL((sample_kernel<true>), dim3(blocks), dim3(256), 0, st, feat, f, n0, n1, n2, rel, a, mode, out);
+  else
+    hipLaunchKernelGGL((sample_kernel<false>), dim3(blocks), dim3(256), 0, st, feat, f, n0, n1, n2, rel, a, mode, out);
+  return vittf_check_launch();
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox) {
+  if (classes <= 0 || nvox <= 0) return 0;
+  // [max bits per class | transposed query chunk (F <= 4096) | fp32 class maps]
+  return align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4) + (size_t)classes * (size_t)nvox * 4;
+}
+
+extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
+                                const int32_t* class_start_host, int32_t classes, int32_t big_a_mean, int32_t o0,
+                                int32_t o1, int32_t o2, uint8_t* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!feat || !qf || !class_start_host || !out || !ws) return VITTF_ERR_INVALID_ARG;
+  if (f <= 0 || f > 4096 || n0 <= 0 || n1 <= 0 || n2 <= 0 || classes <= 0 || o0 <= 0 || o1 <= 0 || o2 <= 0)
+    return VITTF_ERR_INVALID_ARG;
+  const int64_t nvox = (int64_t)n0 * n1 * n2;
+  if (ws_bytes < vittf_similarity_workspace_bytes(classes, nvox)) return VITTF_ERR_WORKSPACE;
+  if (class_start_host[0] != 0) return VITTF_ERR_INVALID_ARG;
+  for (int c = 0; c < classes; ++c)
+    if (class_start_host[c + 1] <= class_start_host[c]) return VITTF_ERR_INVALID_ARG;  // empty class: caller drops it
+  if (((uintptr_t)feat & 7) != 0) return VITTF_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  char* wsb = (char*)ws;
+  unsigned* maxbits = (unsigned*)wsb;
+  float* qf_t = (float*)(wsb + align256((size_t)classes * 4));
+  float* sim = (float*)(wsb + align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4));
+  if (hipMemsetAsync(maxbits, 0, (size_t)classes * 4, st) != hipSuccess) return VITTF_ERR_LAUNCH;
+
+  const int total_a = class_start_host[classes];
+  const int64_t threads = (nvox + VPT - 1) / VPT;
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+  // walk the annotation list in chunks of ACH; a chunk may span several (at most MAXC) classes
+  int a0 = 0;
+  while (a0 < total_a) {
+    SimChunk ch;
+    int c_first = 0;
+    while (class_start_host[c_first + 1] <= a0) ++c_first;
+    ch.c0 = c_first;
+    int n = 0, c = c_first;
+    while (n < ACH && a0 + n < total_a) {
+      while (class_start_host[c + 1] <= a0 + n) ++c;
+      if (c - c_first >= MAXC) break;
+      ch.cls[n] = c - c_first;
+      ++n;
+    }
+    ch.n_ann = n;
+    for (int i = n; i < ACH; ++i) ch.cls[i] = -1;
+    ch.nc = ch.cls[n - 1] + 1;
+    for (int i = 0; i < MAXC; ++i) { ch.first[i] = ch.last[i] = 0; ch.count[i] = 1.f; }
+    for (int i = 0; i < ch.nc; ++i) {
+      const int cc = c_first + i;
+      ch.first[i] = class_start_host[cc] >= a0;
+      ch.last[i] = class_start_host[cc + 1] <= a0 + n;
+      ch.count[i] = (float)(class_start_host[cc + 1] - class_start_host[cc]);
+    }
+    hipLaunchKernelGGL(transpose_queries, dim3((f * ACH + 255) / 256), dim3(256), 0, st, qf, f, a0, n, qf_t);
+    if (big_a_mean)
+      hipLaunchKernelGGL((sim_accumulate<true>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, sim, maxbits);
+    else
+      hipLaunchKernelGGL((sim_accumulate<false>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, sim, maxbits);
+    a0 += n;
+  }
+  const int64_t total_out = (int64_t)classes * o0 * o1 * o2;
+  int64_t qblocks = (total_out + 255) / 256;
+  if (qblocks > 8192) qblocks = 8192;
+  hipLaunchKernelGGL(sim_quantize, dim3((unsigned)qblocks), dim3(256), 0, st, sim, maxbits, classes, n0, n1, n2, o0, o1,
+                     o2, out);
+  return vittf_check_launch();
+}
+
+extern "C" int vittf_assign_labels(const uint8_t* sims, int32_t classes, int64_t n, const int32_t* thr_host,
+                                   uint8_t* labels, void* stream) {
+  if (!sims || !thr_host || !labels || classes <= 0 || classes > 16 || n <= 0) return VITTF_ERR_INVALID_ARG;
+  LabelArgs a;
+  a.classes = classes;
+  for (int i = 0; i < 16; ++i) a.thr[i] = i < classes ? thr_host[i] : 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(labels_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sims, n, a, labels);
+  return vittf_check_launch();
+}

@@ -1,0 +1,82 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of libvittf.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vittf.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;    // one MFMA A/B fragment: 8 x 16-bit = 4 VGPRs
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---- 16-bit conversions (round to nearest even; plain casts lower to v_cvt_pk_bf16_f32 / v_cvt_f16_f32) ----
+template <int DT> __device__ __forceinline__ unsigned short f32_to_h16(float x) {
+  if constexpr (DT == VITTF_BF16) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, b);
+  } else {
+    _Float16 h = (_Float16)x;
+    return __builtin_bit_cast(unsigned short, h);
+  }
+}
+template <int DT> __device__ __forceinline__ float h16_to_f32(unsigned short u) {
+  if constexpr (DT == VITTF_BF16) {
+    return __uint_as_float(((unsigned)u) << 16);
+  } else {
+    return (float)__builtin_bit_cast(_Float16, u);
+  }
+}
+__device__ __forceinline__ unsigned short f32_to_f16bits(float x) { return f32_to_h16<VITTF_FP16>(x); }
+__device__ __forceinline__ float f16bits_to_f32(unsigned short u) { return h16_to_f32<VITTF_FP16>(u); }
+
+template <int DT> __device__ __forceinline__ unsigned pack2_h16(float lo, float hi) {
+  return (unsigned)f32_to_h16<DT>(lo) | ((unsigned)f32_to_h16<DT>(hi) << 16);
+}
+
+// ---- MFMA 32x32x16, fp32 accumulate.  Lane l: A[row l&31][k 8(l>>5)+j], B[k 8(l>>5)+j][col l&31];
+//      C/D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5) for register r of 16. ----
+template <int DT> __device__ __forceinline__ f32x16_t mfma32(s16x8_t a, s16x8_t b, f32x16_t c) {
+  if constexpr (DT == VITTF_BF16) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+}
+// row of accumulator register r (0..15) inside the 32x32 tile, for lane half h
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- LDS image of a [rows][64 x 16-bit] operand tile (128-byte rows) read with ds_read_b128 ----
+// Two rows share one 256-byte bank row; the 16 chunk slots of a row pair are XORed with the pair index so
+// that the 16-lane groups of ds_read_b128 (rows 0-3,12-15,20-27 / ...) hit 16 distinct 16-byte slots.
+// Chunk c (0..7, 8 elements each) of row r lives at byte offset tile_off(r, c).
+__device__ __forceinline__ int tile_off(int r, int c) {
+  const int p = r >> 1;
+  const int slot = (((r & 1) << 3) | c) ^ (p & 15);
+  return ((p << 4) | slot) << 4;
+}
+// inverse: linear 16-byte position q of the image -> (row, chunk); used to pre-swizzle the SOURCE address
+// of global_load_lds, whose LDS destination is always lane-linear.
+__device__ __forceinline__ void tile_pos(int q, int& r, int& c) {
+  const int p = q >> 4;
+  const int slot = (q & 15) ^ (p & 15);
+  r = (p << 1) | (slot >> 3);
+  c = slot & 7;
+}
+
+// XCD-aware, bijective block remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each of
+// the 8 residue classes a contiguous range of logical work items (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+static inline int vittf_check_launch() {
+  return hipGetLastError() == hipSuccess ? VITTF_OK : VITTF_ERR_LAUNCH;
+}

@@ -1,0 +1,153 @@
+// Feature-volume epilogue: slice-axis average pooling + token-major -> feature-major transpose, and the
+// fp16 z + y + x sum over the per-axis pooled volumes gathered from all ranks.
+//
+// Replaces k[:, 1:].view(S, f0, f1, D).permute(0, 3, 1, 2).permute(permute_out) (infer.py:201-203),
+// torch.nn.AdaptiveAvgPool3d(feat_out_sz) (infer.py:329; in-plane it is the identity because the token grid
+// already equals feat_out_sz, only the slice axis is reduced) and the running fp16 sum of infer.py:330-332.
+// HBM-bound byte shuffling: 16-byte loads along the feature dim, an LDS transpose, 128-byte store runs.
+#include "vittf_common.h"
+
+namespace {
+
+constexpr int PT = 64;  // tile: 64 items of the fast output dim x 64 features
+
+struct PoolArgs {
+  const unsigned short* k;
+  int k_slice0, k_nslices, total_slices, n_out, win0, nwin, f0, f1, d;
+  unsigned short* dst;
+  int64_t sd, sw, sr, sc;
+  int fast_is_win;  // 1: the window index is the contiguous output dim, 0: the token column is
+  int tiles_fast;   // tiles along the fast dim
+};
+
+__global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
+  __shared__ unsigned short tile[PT][PT + 2];
+  const int tid = threadIdx.x;
+  // blockIdx.x = ((outer1 * outer2) * tiles_fast + ft) * d_tiles + dt
+  const int d_tiles = a.d / PT;
+  int bid = blockIdx.x;
+  const int dt = bid % d_tiles; bid /= d_tiles;
+  const int ft = bid % a.tiles_fast; bid /= a.tiles_fast;
+  int row, col0, win0, n_items;
+  if (a.fast_is_win) {        // outer = (row, col), items = windows
+    col0 = bid % a.f1; row = bid / a.f1;
+    win0 = ft * PT;
+    n_items = min(PT, a.nwin - win0);
+  } else {                    // outer = (row, window), items = columns
+    win0 = bid % a.nwin; row = bid / a.nwin;
+    col0 = ft * PT;
+    n_items = min(PT, a.f1 - col0);
+  }
+  const int d0 = dt * PT;
+
+  // ---- phase 1: window mean, 8 features per thread ----
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int item = (tid >> 3) + 32 * pass;
+    const int dl = (tid & 7) * 8;
+    if (item < n_items) {
+      const int w = a.win0 + (a.fast_is_win ? win0 + item : win0);
+      const int col = a.fast_is_win ? col0 : col0 + item;
+      const int lo = (int)(((int64_t)w * a.total_slices) / a.n_out);
+      const int hi = (int)((((int64_t)(w + 1)) * a.total_slices + a.n_out - 1) / a.n_out);
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int s = lo; s < hi; ++s) {
+        const int64_t off = (((int64_t)(s - a.k_slice0) * a.f0 + row) * a.f1 + col) * a.d + d0 + dl;
+        const uint4 raw = *reinterpret_cast<const uint4*>(a.k + off);
+        const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[2 * j] += f16bits_to_f32((unsigned short)(u[j] & 0xffff));
+          acc[2 * j + 1] += f16bits_to_f32((unsigned short)(u[j] >> 16));
+        }
+      }
+      const float cnt = (float)(hi - lo);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tile[item][dl + j] = f32_to_f16bits(acc[j] / cnt);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: feature-major stores, consecutive lanes = consecutive items of the contiguous output dim ----
+  const int item = tid & 63;
+  if (item < n_items) {
+    int64_t base = (int64_t)row * a.sr;
+    if (a.fast_is_win) base += (int64_t)col0 * a.sc + (int64_t)(win0 + item) * a.sw;
+    else               base += (int64_t)win0 * a.sw + (int64_t)(col0 + item) * a.sc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int dl = (tid >> 6) + 4 * j;
+      a.dst[(int64_t)(d0 + dl) * a.sd + base] = tile[item][dl];
+    }
+  }
+}
+
+__device__ __forceinline__ float f16_round(float v) { return f16bits_to_f32(f32_to_f16bits(v)); }
+
+__global__ __launch_bounds__(256) void assemble_sum_kernel(const unsigned short* __restrict__ gz,
+                                                           const unsigned short* __restrict__ gy,
+                                                           const unsigned short* __restrict__ gx, int cz, int cy, int cx,
+                                                           int d, int n0, int n1, int n2, unsigned short* __restrict__ out) {
+  const int64_t total = (int64_t)d * n0 * n1 * n2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    int64_t t = e;
+    const int i2 = (int)(t % n2); t /= n2;
+    const int i1 = (int)(t % n1); t /= n1;
+    const int i0 = (int)(t % n0);
+    const int f = (int)(t / n0);
+    // slab layouts written by pool_kernel: rank-major, then (D, dims with the axis' dim cut to `chunk`)
+    const int rz = i2 / cz, rx = i0 / cx, ry = i1 / cy;
+    const int64_t oz = ((((int64_t)rz * d + f) * n0 + i0) * n1 + i1) * cz + (i2 - rz * cz);
+    const int64_t oy = ((((int64_t)ry * d + f) * n0 + i0) * cy + (i1 - ry * cy)) * n2 + i2;
+    const int64_t ox = ((((int64_t)rx * d + f) * cx + (i0 - rx * cx)) * n1 + i1) * n2 + i2;
+    const float z = f16bits_to_f32(gz[oz]), y = f16bits_to_f32(gy[oy]), x = f16bits_to_f32(gx[ox]);
+    // 0.0 + z is exact; each fp16 + fp16 add is rounded once (the fp32 sum of two halves is exact)
+    out[e] = f32_to_f16bits(f16_round(z + y) + x);
+  }
+}
+
+}  // namespace
+
+extern "C" int vittf_pool_slices(const uint16_t* k_slices, int32_t k_slice0, int32_t k_nslices, int32_t total_slices,
+                                 int32_t n_out, int32_t win0, int32_t nwin, int32_t f0, int32_t f1, int32_t d,
+                                 uint16_t* dst, int64_t dst_stride_d, int64_t dst_stride_win, int64_t dst_stride_row,
+                                 int64_t dst_stride_col, void* stream) {
+  if (!k_slices || !dst || total_slices <= 0 || n_out <= 0 || nwin <= 0 || win0 < 0 || win0 + nwin > n_out)
+    return VITTF_ERR_INVALID_ARG;
+  if (f0 <= 0 || f1 <= 0 || d <= 0 || d % PT != 0 || k_nslices <= 0 || k_slice0 < 0) return VITTF_ERR_INVALID_ARG;
+  if (((uintptr_t)k_slices & 15) != 0) return VITTF_ERR_INVALID_ARG;
+  // every slice touched by the requested windows must be resident
+  const int64_t lo = ((int64_t)win0 * total_slices) / n_out;
+  const int64_t hi = (((int64_t)(win0 + nwin)) * total_slices + n_out - 1) / n_out;
+  if (lo < k_slice0 || hi > (int64_t)k_slice0 + k_nslices || hi > total_slices) return VITTF_ERR_INVALID_ARG;
+  PoolArgs a;
+  a.k = k_slices; a.k_slice0 = k_slice0; a.k_nslices = k_nslices; a.total_slices = total_slices; a.n_out = n_out;
+  a.win0 = win0; a.nwin = nwin; a.f0 = f0; a.f1 = f1; a.d = d; a.dst = dst;
+  a.sd = dst_stride_d; a.sw = dst_stride_win; a.sr = dst_stride_row; a.sc = dst_stride_col;
+  a.fast_is_win = (dst_stride_win == 1 && dst_stride_col != 1) ? 1 : 0;
+  int64_t blocks;
+  if (a.fast_is_win) { a.tiles_fast = (nwin + PT - 1) / PT; blocks = (int64_t)f0 * f1 * a.tiles_fast * (d / PT); }
+  else               { a.tiles_fast = (f1 + PT - 1) / PT;   blocks = (int64_t)f0 * nwin * a.tiles_fast * (d / PT); }
+  if (blocks > 0x7fffffff) return VITTF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(pool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return vittf_check_launch();
+}
+
+extern "C" int vittf_assemble_sum(const uint16_t* gz, const uint16_t* gy, const uint16_t* gx, int32_t nranks,
+                                  const int32_t chunk[3], int32_t d, int32_t n0, int32_t n1, int32_t n2, uint16_t* out,
+                                  void* stream) {
+  if (!gz || !gy || !gx || !out || !chunk || nranks <= 0 || d <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0)
+    return VITTF_ERR_INVALID_ARG;
+  // chunk[a] windows per rank along volume dim a; nranks * chunk must cover the dim
+  if (chunk[0] <= 0 || chunk[1] <= 0 || chunk[2] <= 0) return VITTF_ERR_INVALID_ARG;
+  if ((int64_t)nranks * chunk[0] < n0 || (int64_t)nranks * chunk[1] < n1 || (int64_t)nranks * chunk[2] < n2)
+    return VITTF_ERR_INVALID_ARG;
+  const int64_t total = (int64_t)d * n0 * n1 * n2;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(assemble_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gz, gy, gx,
+                     chunk[2], chunk[1], chunk[0], d, n0, n1, n2, out);
+  return vittf_check_launch();
+}
