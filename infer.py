@@ -1,0 +1,267 @@
+"""Drop-in for the reference's ``infer.py``: slice-wise DINO ViT K-feature volumes, MI355X-native.
+
+Same module surface and CLI as /root/reference/infer.py (helpers :10-40, sample_features3d :48,
+compute_qkv :130, load_data :212, load_model :239, handle_output_path :266, CLI flags :296-306,
+output naming :279, file layout :337-340) -- the ViT forward, pooling and axis sum run in the HIP
+kernels of libvittf instead of stock PyTorch ops.  There is no CPU path: ``--cpu`` is accepted for flag
+compatibility and refused with exit code 1.
+
+Differences a caller can observe:
+  * the model comes from a LOCAL DINO state dict (``--weights``, ``$VITTF_WEIGHTS`` or the torch-hub
+    checkpoint cache) or from seeded synthetic weights (``--synthetic-weights SEED``); nothing is
+    fetched from the network (the reference calls torch.hub.load, :42-43)
+  * ``--batch-size`` no longer changes memory behaviour: slices are independent and the engine picks its
+    own batch (results do not depend on it); ``--engine-dtype`` selects bf16 (default) or fp16 MFMA operands
+  * launched under torchrun, the slices of each axis are sharded over the ranks and reassembled with one
+    RCCL all-gather per axis; rank 0 writes the file
+"""
+import os
+import sys
+import time
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+import vit_tf_amd as vt
+
+in_mean = [0.485, 0.456, 0.406]
+in_std = [0.229, 0.224, 0.225]
+
+
+# ---------------------------------------------------------------------------- tensor helpers (:10-37)
+def make_nd(t, n):
+    """Prepend singleton dims until `t` is n-dimensional."""
+    if n < t.ndim:
+        raise Exception(f'make_nd cannot reduce cardinality. Your Tensor.ndim={t.ndim} > n={n}.')
+    return t[(None,) * (n - t.ndim)] if n > t.ndim else t
+
+
+def make_3d(t):
+    return make_nd(t, 3)
+
+
+def make_4d(t):
+    return make_nd(t, 4)
+
+
+def make_5d(t):
+    return make_nd(t, 5)
+
+
+def norm_minmax(t):
+    lo, hi = t.min(), t.max()
+    return (t - lo) / (hi - lo)
+
+
+def norm_mean_std(t, mu=0, std=1):
+    tf = t.float()
+    return (tf - tf.mean()) * std / tf.std() + mu
+
+
+# ---------------------------------------------------------------------------- model (:42-46, :239-264)
+_MODEL_OPTS = {'weights': None, 'synthetic_seed': None, 'dtype': 'bf16'}
+
+
+def get_dino_model(name):
+    """HIP engine for ``dino_<name>``.  Weight source, in order: --weights / $VITTF_WEIGHTS, the local
+    torch-hub checkpoint cache, --synthetic-weights / $VITTF_SYNTHETIC_WEIGHTS.  No network access."""
+    path = _MODEL_OPTS['weights'] or vt.find_local_checkpoint(name)
+    seed = _MODEL_OPTS['synthetic_seed']
+    if seed is None and os.environ.get('VITTF_SYNTHETIC_WEIGHTS') is not None:
+        seed = int(os.environ['VITTF_SYNTHETIC_WEIGHTS'])
+    if path is not None:
+        sd = vt.load_state_dict_file(path)
+    elif seed is not None:
+        print(f'Using seeded synthetic {name} weights (seed {seed}); features are NOT DINO features.')
+        sd = vt.synthetic_state_dict(name, seed)
+    else:
+        print(f'No local checkpoint for dino_{name}: pass --weights PATH (DINO state dict) or '
+              f'--synthetic-weights SEED. This build never downloads weights.')
+        sys.exit(1)
+    return vt.HipViT(sd, name, dtype=_MODEL_OPTS['dtype'])
+
+
+def get_dinov2_model(name):
+    print('DINOv2 (patch 14) models are not supported by the HIP engine.')
+    sys.exit(1)
+
+
+def load_model(args):
+    """(:239-264) -> (model name, constructor, patch size); exits with 1 on contradictory flags."""
+    if args.dino_model and args.dino2_model:
+        print('Both --dino-model and --dino2-model were set. Please only set one of them.')
+        sys.exit(1)
+    if args.dino2_model:
+        args.dino_model = args.model = args.dino2_model
+        return args.dino2_model, get_dinov2_model, 14
+    if not args.dino_model:
+        print('No DINO/DINOv2 model specified, using default: vits8')
+        args.dino_model = 'vits8'
+    args.model = args.dino_model
+    return args.dino_model, get_dino_model, 8 if args.dino_model[-1] == '8' else 16
+
+
+# ---------------------------------------------------------------------------- sampling helpers (:48-126)
+def sample_features3d(feat_vol, rel_coords, mode='nearest'):
+    """(:48-72) feat_vol ([M,] F, W, H, D), rel_coords ([M,] C, A, 3) -> ([M,] C, A, F); on the GPU."""
+    return vt.sample_features3d(feat_vol, rel_coords, mode)
+
+
+def resample_topk(feat_vol, sims, K=8, similarity_exponent=2.0, feature_sampling_mode='nearest'):
+    raise NotImplementedError('resample_topk is not on the round-1 hot path (never called in the reference; SURVEY.md 8f-2)')
+
+
+def take_most_dissimilar(features, num_prototypes=35, measure='cosine'):
+    raise NotImplementedError('take_most_dissimilar is not on the round-1 hot path (SURVEY.md 8f-2)')
+
+
+def _noop(x, **kwargs):
+    return x
+
+
+# ---------------------------------------------------------------------------- extraction (:130-210)
+def compute_qkv(vol, model, patch_size, im_sizes, pool_fn=_noop, batch_size=1, slice_along='z',
+                return_keys=['q', 'k', 'v'], dev=None, typ=None, group=None):
+    """(:130-210) features of the last block's qkv projection for every slice of one axis.
+
+    Returns {key: CPU tensor} with, like the reference, (F, W', H', S)-style un-pooled layout for
+    ``pool_fn=_noop`` and the pooled (F, *output_size) volume when ``pool_fn`` is an
+    ``AdaptiveAvgPool3d``; any other callable is applied to the un-pooled device tensor.
+    `model` is a HipViT; `dev` / `typ` are accepted for signature compatibility (the engine's device
+    and MFMA dtype are properties of the model)."""
+    if isinstance(return_keys, str):
+        return_keys = [return_keys]
+    if patch_size != model.patch_size:
+        raise ValueError(f'patch_size {patch_size} != model patch size {model.patch_size}')
+    dvol = vt.DeviceVolume(vol, model.device)
+    eb = max(int(batch_size), vt.extract.DEFAULT_ENGINE_BATCH)
+    out = {}
+    for key in return_keys:
+        part = vt.extract.PARTS[key]
+        if isinstance(pool_fn, torch.nn.AdaptiveAvgPool3d):
+            size = pool_fn.output_size
+            size = (size,) * 3 if isinstance(size, int) else tuple(size)
+            res = vt.pooled_axis(None, model, slice_along, tuple(im_sizes), size, eb, part, group, dvol)
+        else:
+            sl = vt.AXIS_DIMS[slice_along][0]
+            g, _ = vt.extract.axis_features(model, dvol, slice_along, tuple(im_sizes), dvol.shape[sl], eb, part, group)
+            res = pool_fn(vt.extract.assemble_axis(g, slice_along, dvol.shape[sl]))
+        out[key] = res.cpu()
+    return out
+
+
+# ---------------------------------------------------------------------------- I/O (:212-237, :266-288)
+def load_data(data_path):
+    data_path = Path(data_path)
+    if not data_path.exists():
+        print(f'Invalid argument for --data-path (File does not exist): {data_path}')
+        sys.exit(1)
+    print(f'Attempting to load {data_path}.')
+    if data_path.suffix in ('.pt', '.pth'):
+        data = torch.load(data_path, weights_only=False)
+        vol = data['vol'] if isinstance(data, dict) else data
+    elif data_path.suffix == '.npy':
+        data = np.load(data_path, allow_pickle=True)
+        arr = data[()]['vol'] if data.dtype == object else data
+        vol = torch.from_numpy(np.asarray(arr).astype(np.float32))
+    else:
+        print(f'Unsupported file extension: {data_path.suffix}')
+        sys.exit(1)
+    print(f'Loaded volume: {vol.shape} of type {vol.dtype}.')
+    assert vol.ndim == 3
+    return vol
+
+
+def handle_output_path(args):
+    data_path = Path(args.data_path)
+    if not args.cache_path:
+        stem = f'{data_path.stem}_{args.model.replace("/", "_")}_{args.slice_along}_features{args.feature_output_size}'
+        args.cache_path = data_path.parent / f'{stem}{data_path.suffix}'
+    cache_path = Path(args.cache_path)
+    if cache_path.exists() and not args.overwrite:
+        print(f'Cache file already exists: {cache_path}. Use --overwrite to overwrite.')
+        sys.exit(1)
+    if not os.access(os.path.dirname(str(cache_path)) or os.getcwd(), os.W_OK):
+        print(f'Invalid argument for --cache-path (Cannot write to location): {args.cache_path}')
+        sys.exit(1)
+    return cache_path
+
+
+def save_features(qkv, cache_path):
+    """(:337-340) {'k': fp16 (F, W', H', D')} as .pt (torch.save) or .npy (pickled dict)."""
+    cache_path = Path(cache_path)
+    if cache_path.suffix in ('.pt', '.pth'):
+        torch.save(qkv, cache_path)
+    elif cache_path.suffix == '.npy':
+        np.save(cache_path, {k: v.numpy() for k, v in qkv.items()})
+
+
+def _init_distributed():
+    """One process per GPU under torchrun (RANK/LOCAL_RANK/WORLD_SIZE); single process otherwise."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 1
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if not torch.distributed.is_initialized():
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+    return torch.distributed.get_rank(), world
+
+
+def main(argv=None):
+    from argparse import ArgumentParser
+    dino_archs = ['vits16', 'vits8', 'vitb16', 'vitb8']
+    dino2_archs = ['vits14', 'vitb14', 'vitl14', 'vitg14']
+    parser = ArgumentParser('Infer DINO features from saved volume')
+    parser.add_argument('--data-path', type=str, required=True, help='Path to the saved volume')
+    parser.add_argument('--cache-path', type=str, default=None, help='Path to save computed qkv features to.')
+    parser.add_argument('--dino-model', type=str, choices=dino_archs, default=None, help='DINO model to use')
+    parser.add_argument('--dino2-model', type=str, choices=dino2_archs, default=None, help='DINOv2 model to use')
+    parser.add_argument('--slice-along', type=str, choices=['x', 'y', 'z', 'all'], default='all',
+                        help='Along which axis to slice volume, as it is fed slice-wise to DINO')
+    parser.add_argument('--batch-size', type=int, default=1, help='Feed volume through network in batches')
+    parser.add_argument('--feature-output-size', type=int, default=64,
+                        help='Produces a features map with aspect ratio of input volume with this value as y resolution. Only if --slice-along ALL')
+    parser.add_argument('--cpu', action='store_true', help='Use CPU only (not available in the MI355X build)')
+    parser.add_argument('--overwrite', action='store_true', help='Overwrite existing cache files')
+    # additions of the MI355X build
+    parser.add_argument('--weights', type=str, default=None, help='Local DINO state dict (.pth)')
+    parser.add_argument('--synthetic-weights', type=int, default=None, metavar='SEED', help='Use seeded synthetic weights')
+    parser.add_argument('--engine-dtype', type=str, choices=['bf16', 'fp16'], default='bf16', help='MFMA operand type')
+    args = parser.parse_args(argv)
+
+    if args.cpu:
+        print('--cpu: this build has no CPU path (the hot path runs only on MI355X / gfx950).')
+        sys.exit(1)
+    _MODEL_OPTS.update(weights=args.weights, synthetic_seed=args.synthetic_weights, dtype=args.engine_dtype)
+    dino_model, dino_model_fn, patch_size = load_model(args)
+    rank, world = _init_distributed()
+    cache_path = handle_output_path(args) if rank == 0 else None
+
+    vol = load_data(args.data_path)
+    im_sz, feat_out_sz = vt.sizing(tuple(vol.shape), args.feature_output_size, patch_size)
+    print(f'Input image size: {im_sz}')
+    model = dino_model_fn(dino_model)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    eb = max(args.batch_size, vt.extract.DEFAULT_ENGINE_BATCH)
+    feats = vt.feature_volume(vol, model, args.feature_output_size, args.slice_along, eb)
+    if args.slice_along == 'all':
+        qkv = defaultdict(float)           # the reference saves a defaultdict in 'all' mode (:328)
+        qkv['k'] = feats.cpu()
+    else:
+        qkv = {'k': feats.cpu()}
+    if rank == 0:
+        print('k', ':', qkv['k'].shape)
+        print(f'Computed qkv along {args.slice_along} in {time.time() - t0}s, saving now to: {cache_path}')
+        save_features(qkv, cache_path)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    sys.exit(0)
+
+
+if __name__ == '__main__':
+    main()

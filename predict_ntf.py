@@ -1,0 +1,161 @@
+"""Drop-in for the reference's ``predict_ntf.py``: per-class similarity volumes + label volume, MI355X-native.
+
+Same function and CLI surface as /root/reference/predict_ntf.py (compute_similarities :24-101, flags
+:105-112, directory contract :119-172, label assignment :203-215, outputs :216, :249-250); the query
+sampling, the voxel x query contraction, threshold / power / class mean, quantisation and the label
+arg-max run in libvittf's HIP kernels (``--gpu`` is implied: there is no CPU path).  The bilateral-solver
+post-process (``--bilateral-solver``) is not part of this build yet and exits with 1.
+"""
+import json
+import sys
+import time
+from argparse import ArgumentParser
+from pathlib import Path
+from pprint import pprint
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import vit_tf_amd as vt
+from vit_tf_amd.samplers import sample_uniform, sample_surface, sample_both
+from infer import make_3d, make_4d, make_5d, sample_features3d, norm_minmax   # noqa: F401  (re-exported like the reference)
+
+sampling_modes = {
+    'uniform': sample_uniform,
+    'surface': sample_surface,
+    'both': sample_both,
+    'annotated': lambda *args, **kwargs: None,
+}
+
+ct_org_names = ['liver', 'bladder', 'lung', 'kidney', 'bone']
+ct_org_thresholds = [0.486, 0.264, 0.236, 0.68, 0.291]
+
+
+def compute_similarities(volume, features, annotations, bilateral_solver=False):
+    """(:24-101) volume (W, H, D), features (F, W', H', D'), annotations {name: (N, 3)} ->
+    {name: uint8 (W//2, H//2, D//2)} (CPU tensors)."""
+    return vt.compute_similarities(volume, features, annotations, bilateral_solver=bilateral_solver)
+
+
+def assign_labels(similarities):
+    """(:203-215) running maximum over the class maps with the CT-ORG thresholds -> uint8 numpy volume."""
+    return vt.assign_labels(similarities, ct_org_thresholds)
+
+
+def _metrics(labels, pred, names):
+    """(:228-246) sklearn when it is installed, the same quantities from a confusion matrix otherwise."""
+    y, p = labels.reshape(-1), pred.reshape(-1)
+    try:
+        from sklearn.metrics import precision_recall_fscore_support, jaccard_score, confusion_matrix, accuracy_score
+        prec, rec, f1, _ = precision_recall_fscore_support(y, p, average=None)
+        cm = confusion_matrix(y, p)
+        acc = accuracy_score(y, p)
+        iou = jaccard_score(y, p, average=None)
+    except ImportError:
+        k = int(max(y.max(), p.max())) + 1
+        cm = np.zeros((k, k), dtype=np.int64)
+        np.add.at(cm, (y.astype(np.int64), p.astype(np.int64)), 1)
+        tp = np.diag(cm).astype(np.float64)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            prec = np.nan_to_num(tp / cm.sum(0)); rec = np.nan_to_num(tp / cm.sum(1))
+            f1 = np.nan_to_num(2 * prec * rec / (prec + rec)); iou = np.nan_to_num(tp / (cm.sum(0) + cm.sum(1) - tp))
+        acc = tp.sum() / cm.sum()
+    return {
+        'mAcc': float(acc),
+        'precision': dict(zip(names, prec.tolist())), 'mPrec': float(prec.mean()),
+        'recall': dict(zip(names, rec.tolist())), 'mRec': float(rec.mean()),
+        'f1': dict(zip(names, f1.tolist())), 'mF1': float(f1.mean()),
+        'iou': dict(zip(names, iou.tolist())), 'mIoU': float(iou.mean()),
+        'confusion_matrix': dict(zip(names, cm.tolist())),
+    }
+
+
+def main(argv=None):
+    parser = ArgumentParser()
+    parser.add_argument('--data', type=str, help='Path to features, annotations, volume etc.')
+    parser.add_argument('--bilateral-solver', action='store_true', help='Use bilateral solver')
+    parser.add_argument('--load-sims', action='store_true', help='Load similarities from file')
+    parser.add_argument('--num-samples', type=float, default=0.0, help='Number of samples to use for each NTF')
+    parser.add_argument('--sampling-mode', type=str, choices=['uniform', 'surface', 'both'], default='both', help='Sampling mode')
+    parser.add_argument('--gpu', action='store_true', help='Use GPU (always on in this build)')
+    args = parser.parse_args(argv)
+    if args.bilateral_solver:
+        print('--bilateral-solver is not available in this build yet.')
+        sys.exit(1)
+
+    d = Path(args.data)
+    if args.num_samples == 0.0:
+        args.sampling_mode = 'annotated'
+    bls = 'bls' if args.bilateral_solver else ''
+    tag = f'{args.num_samples}{args.sampling_mode}{bls}'
+    if (d / f'ntf_pred{tag}.npy').exists():
+        print(f'Already inferred NTF preds for {d} using sampling mode {args.sampling_mode} and {args.num_samples} samples')
+        sys.exit(0)
+    print(f'Inferring for {d} using sampling mode {args.sampling_mode} and {args.num_samples} samples')
+
+    feat_fns = [p for p in d.iterdir() if 'features' in str(p) and 'pred' not in str(p)]
+    if not feat_fns:
+        raise ValueError(f'No features found in {d}')
+    feat_fn = max(feat_fns, key=lambda p: p.stat().st_size)
+    if len(feat_fns) > 1:
+        print(f'Found multiple features in {d}. Using largest one {feat_fn.name}.')
+
+    volume = np.flip(np.load(d / 'volume.npy', allow_pickle=True).astype(np.float32), axis=-3).copy()
+    labels = None
+    if (d / 'labels.npy').exists():
+        labels = np.flip(np.load(d / 'labels.npy', allow_pickle=True)[()], axis=-3).copy()
+    else:
+        assert args.num_samples == 0.0, 'Cannot sample labels if they are not provided'
+    features = np.load(feat_fn, allow_pickle=True)[()]
+    features = torch.as_tensor(features['k'] if isinstance(features, dict) else features).squeeze()
+
+    if args.num_samples == 0.0:
+        annotations = np.load(d / 'annotations.npy', allow_pickle=True)[()]
+    elif args.num_samples > 0.0:
+        draw = sampling_modes[args.sampling_mode]
+        annotations = {}
+        for i in range(1, int(labels.max()) + 1):
+            mask = torch.as_tensor(labels == i)
+            total = int(mask.sum().item())
+            n = min(int(args.num_samples), total) if args.num_samples > 1.0 else int(args.num_samples * total)
+            if n > 0:
+                annotations[f'ntf{i}'] = draw(mask, n, thin_to_reasonable=True)
+    else:
+        raise Exception(f'Invalid value for --num-samples: {args.num_samples}')
+
+    print(f'Computing similarties for {tuple(volume.shape)} with features {tuple(features.shape)}')
+    t0 = time.time()
+    t1 = t0
+    if args.load_sims:
+        similarities = {k: torch.as_tensor(v) for k, v in np.load(d / 'similarities.npy', allow_pickle=True)[()].items()}
+        t2 = t1
+    else:
+        t1 = time.time()
+        if sum(int(torch.as_tensor(v).shape[0]) for v in annotations.values()) > 10000:     # (:185-187) one class per call
+            similarities = {k: compute_similarities(volume, features, {k: v})[k] for k, v in annotations.items()}
+        else:
+            similarities = compute_similarities(volume, features, annotations)
+        torch.cuda.synchronize()
+        t2 = time.time()
+    print('Similarities:', {k: v.shape for k, v in similarities.items()})
+    pred = assign_labels(similarities)
+    np.save(d / f'ntf_pred{tag}.npy', pred)
+    if tuple(pred.shape[-3:]) != tuple(volume.shape[-3:]):
+        pred = F.interpolate(make_5d(torch.as_tensor(pred)), tuple(volume.shape[-3:]), mode='nearest').squeeze().numpy()
+    print('Pred:', pred.shape, pred.min(), pred.max())
+    print('NTF fit time:', t1 - t0)
+    print('NTF predict time:', t2 - t1)
+    if labels is None:
+        sys.exit(0)
+    ntf_metrics = _metrics(labels, pred, ['background'] + list(annotations.keys()))
+    ntf_metrics['fit_time'] = t1 - t0
+    ntf_metrics['predict_time'] = t2 - t1
+    print('NTF Metrics:')
+    pprint(ntf_metrics)
+    with open(d / f'ntf_metrics{tag}.json', 'w') as f:
+        json.dump(ntf_metrics, f)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,181 @@
+"""Feature-volume extraction: volume -> (F, W', H', D') fp16 K-feature volume, on one or several GPUs.
+
+Host-side mirror of infer.py:130-210 (compute_qkv) and infer.py:314-333 (the __main__ driver): the
+sizing rule, the per-axis slice views, the slice loop, slice-axis pooling and the z -> y -> x fp16 sum.
+All arithmetic happens in libvittf kernels; this module only sizes buffers, walks slice ranges and (for
+more than one rank) exchanges pooled slabs with ONE all-gather per axis over RCCL.
+
+Sharding: slices of an axis are independent, so rank r of G owns the contiguous
+block of pooling windows [r*c, (r+1)*c), c = ceil(n_out / G), runs exactly the slices those windows
+touch, pools them locally into a slab, and the slabs are all-gathered; every rank then forms
+fp16(fp16(z + y) + x) for the whole volume.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+# axis -> (sliced volume dim, (volume dim of image rows, volume dim of image cols))      infer.py:138-147
+AXIS_DIMS = {'z': (2, (0, 1)), 'y': (1, (0, 2)), 'x': (0, (1, 2))}
+DEFAULT_ENGINE_BATCH = 32
+PARTS = {'q': 0, 'k': 1, 'v': 2}
+
+
+def sizing(vol_shape, feature_output_size, patch_size):
+    """infer.py:317-319: (im_sz, feat_out_sz)."""
+    ref_fact = sorted(vol_shape[-3:])[1] / feature_output_size
+    im_sz = tuple(int(patch_size * (d // ref_fact)) for d in vol_shape[-3:])
+    return im_sz, tuple(d // patch_size for d in im_sz)
+
+
+def window_bounds(i, n_in, n_out):
+    """Adaptive-pool window i: [floor(i*in/out), ceil((i+1)*in/out))."""
+    return (i * n_in) // n_out, -((-(i + 1) * n_in) // n_out)
+
+
+def shard_windows(n_out, rank, world):
+    """Windows owned by `rank`: (first, count, chunk) with chunk = ceil(n_out / world)."""
+    chunk = -(-n_out // world)
+    first = min(rank * chunk, n_out)
+    return first, max(0, min(chunk, n_out - first)), chunk
+
+
+class DeviceVolume:
+    """fp32 copy of the volume in HBM + its global min/max (norm_minmax, infer.py:32-34, 137)."""
+
+    def __init__(self, vol, device):
+        lib = _lib.require_device()
+        vol = torch.as_tensor(vol).squeeze()
+        if vol.ndim != 3:
+            raise ValueError(f'volume must be 3-D, got shape {tuple(vol.shape)}')
+        self.shape = tuple(vol.shape)
+        self.data = vol.to(device=device, dtype=torch.float32).contiguous()
+        self.minmax = torch.empty(2, dtype=torch.float32, device=device)
+        ws = torch.empty(lib.vittf_minmax_workspace_bytes(), dtype=torch.uint8, device=device)
+        _lib.check(lib.vittf_volume_minmax(_lib.ptr(self.data), self.data.numel(), _lib.ptr(self.minmax), _lib.ptr(ws),
+                                           ws.numel(), _lib.stream_ptr()), 'vittf_volume_minmax')
+        self._ws = ws
+
+    def view(self, axis, im_sizes):
+        sl, (a, b) = AXIS_DIMS[axis]
+        st = self.data.stride()
+        return _lib.SliceView(self.data.data_ptr(), st[sl], st[a], st[b], self.shape[a], self.shape[b],
+                              im_sizes[a], im_sizes[b], self.minmax.data_ptr())
+
+
+def _axis_geometry(shape, im_sizes, axis, patch):
+    sl, (a, b) = AXIS_DIMS[axis]
+    return sl, a, b, shape[sl], im_sizes[a] // patch, im_sizes[b] // patch
+
+
+def k_slices(model, dvol, axis, im_sizes, s0, s1, engine_batch=DEFAULT_ENGINE_BATCH, part=1, out=None):
+    """Token-major fp16 features of slices [s0, s1) of one axis: tensor [s1-s0, f0*f1, D] on the device."""
+    _, _, _, _, f0, f1 = _axis_geometry(dvol.shape, im_sizes, axis, model.patch_size)
+    n = s1 - s0
+    per = f0 * f1 * model.embed_dim
+    if out is None:
+        out = torch.empty((n, f0 * f1, model.embed_dim), dtype=torch.float16, device=model.device)
+    view = dvol.view(axis, im_sizes)
+    flat = out.view(-1)
+    for b0 in range(0, n, engine_batch):
+        nb = min(engine_batch, n - b0)
+        model.k_features(view, s0 + b0, nb, flat[b0 * per:], part)
+    return out
+
+
+def _pool_into(lib, kbuf, k_s0, n_slices_total, n_out, win0, nwin, f0, f1, d, dst, strides):
+    sd, sw, sr, sc = strides
+    _lib.check(lib.vittf_pool_slices(_lib.ptr(kbuf), k_s0, kbuf.shape[0], n_slices_total, n_out, win0, nwin, f0, f1, d,
+                                     _lib.ptr(dst), sd, sw, sr, sc, _lib.stream_ptr()), 'vittf_pool_slices')
+
+
+def _slab_shape_strides(axis, d, n, chunk):
+    """Slab of one rank for `axis`: the pooled volume with the axis' dim cut to `chunk` windows.
+    Returns (shape, (stride_d, stride_win, stride_row, stride_col)) in elements."""
+    sl, (a, b) = AXIS_DIMS[axis]
+    dims = list(n)
+    dims[sl] = chunk
+    st = [dims[1] * dims[2], dims[2], 1]
+    return (d, *dims), (dims[0] * dims[1] * dims[2], st[sl], st[a], st[b])
+
+
+def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=DEFAULT_ENGINE_BATCH, part=1, group=None):
+    """Pooled (n_out windows along the slice dim) features of one axis, gathered over the process group.
+
+    Returns (gathered [world, D, *slab_dims] fp16 device tensor, chunk)."""
+    lib = model.lib
+    world = torch.distributed.get_world_size(group) if _dist_on(group) else 1
+    rank = torch.distributed.get_rank(group) if world > 1 else 0
+    sl, a, b, n_slices, f0, f1 = _axis_geometry(dvol.shape, im_sizes, axis, model.patch_size)
+    d = model.embed_dim
+    n = [0, 0, 0]
+    n[sl], n[a], n[b] = n_out, f0, f1
+    win0, nwin, chunk = shard_windows(n_out, rank, world)
+    shape, strides = _slab_shape_strides(axis, d, n, chunk)
+    gathered = torch.zeros((world, *shape), dtype=torch.float16, device=model.device)
+    slab = gathered[rank]
+    if nwin > 0:
+        s0 = window_bounds(win0, n_slices, n_out)[0]
+        s1 = window_bounds(win0 + nwin - 1, n_slices, n_out)[1]
+        kbuf = k_slices(model, dvol, axis, im_sizes, s0, s1, engine_batch, part)
+        _pool_into(lib, kbuf, s0, n_slices, n_out, win0, nwin, f0, f1, d, slab, strides)
+        del kbuf
+    if world > 1:
+        # one exchange step per axis: RCCL all-gather of the pooled slab (in place into `gathered`)
+        torch.distributed.all_gather_into_tensor(gathered.view(-1), slab.reshape(-1).clone(), group=group)
+    return gathered, chunk
+
+
+def _dist_on(group):
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and \
+        torch.distributed.get_world_size(group) > 1
+
+
+def assemble_axis(gathered, axis, n_total):
+    """Single-axis mode: concatenate the ranks' slabs along the slice dim -> (D, ...) (plumbing only)."""
+    sl, _ = AXIS_DIMS[axis]
+    full = torch.cat(list(gathered), dim=1 + sl)
+    return full.narrow(1 + sl, 0, n_total).contiguous()
+
+
+def feature_volume(vol, model, feature_output_size=64, slice_along='all', engine_batch=DEFAULT_ENGINE_BATCH,
+                   part=1, group=None, dvol=None):
+    """infer.py:314-333 on the GPU(s).  Returns the fp16 feature tensor on the device:
+    'all' -> (D, W', H', D') = fp16(fp16(z + y) + x) of the pooled axes; 'x'|'y'|'z' -> un-pooled single axis."""
+    lib = model.lib
+    if dvol is None:
+        dvol = DeviceVolume(vol, model.device)
+    im_sz, feat_out = sizing(dvol.shape, feature_output_size, model.patch_size)
+    if min(im_sz) <= 0:
+        raise ValueError(f'feature_output_size {feature_output_size} gives an empty image size {im_sz}')
+    if slice_along in AXIS_DIMS:
+        sl = AXIS_DIMS[slice_along][0]
+        g, _ = axis_features(model, dvol, slice_along, im_sz, dvol.shape[sl], engine_batch, part, group)
+        return assemble_axis(g, slice_along, dvol.shape[sl])
+    if slice_along != 'all':
+        raise Exception(f'Invalid argument for --slice-along: {slice_along}. Must be x,y,z or all')
+    gathered, chunks = {}, [0, 0, 0]
+    for ax in ('z', 'y', 'x'):
+        sl = AXIS_DIMS[ax][0]
+        gathered[ax], chunks[sl] = axis_features(model, dvol, ax, im_sz, feat_out[sl], engine_batch, part, group)
+    world = gathered['z'].shape[0]
+    out = torch.empty((model.embed_dim, *feat_out), dtype=torch.float16, device=model.device)
+    carr = (C.c_int32 * 3)(*chunks)
+    _lib.check(lib.vittf_assemble_sum(_lib.ptr(gathered['z']), _lib.ptr(gathered['y']), _lib.ptr(gathered['x']), world,
+                                      carr, model.embed_dim, feat_out[0], feat_out[1], feat_out[2], _lib.ptr(out),
+                                      _lib.stream_ptr()), 'vittf_assemble_sum')
+    return out
+
+
+def pooled_axis(vol, model, axis, im_sizes, out_size, engine_batch=DEFAULT_ENGINE_BATCH, part=1, group=None, dvol=None):
+    """compute_qkv(..., pool_fn=AdaptiveAvgPool3d(out_size)) for one axis: (D, *out_size) fp16 on the device."""
+    if dvol is None:
+        dvol = DeviceVolume(vol, model.device)
+    sl, (a, b) = AXIS_DIMS[axis]
+    p = model.patch_size
+    if out_size[a] != im_sizes[a] // p or out_size[b] != im_sizes[b] // p:
+        raise NotImplementedError('in-plane pooling: the HIP path pools the slice axis only (the token grid already '
+                                  'equals feat_out_sz for every sizing infer.py produces, infer.py:317-319)')
+    g, _ = axis_features(model, dvol, axis, im_sizes, out_size[sl], engine_batch, part, group)
+    return assemble_axis(g, axis, out_size[sl])

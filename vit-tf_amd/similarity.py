@@ -1,0 +1,108 @@
+"""Similarity queries against a feature volume, on the GPU through libvittf.
+
+Host-side mirror of sample_features3d (infer.py:48-72), compute_similarities (predict_ntf.py:24-101,
+without the bilateral solver) and the label assignment of predict_ntf.py:203-215.  Same argument
+meaning and return types as the reference functions; the arithmetic is in similarity.hip.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+CT_ORG_THRESHOLDS = (0.486, 0.264, 0.236, 0.68, 0.291)   # predict_ntf.py:208
+
+
+def _device_features(features, device):
+    """Feature volume as a contiguous fp16 (F, n0, n1, n2) device tensor.  Feature files hold fp16
+    (infer.py:134, 337-340), so fp32 inputs that came from such a file convert back exactly."""
+    t = torch.as_tensor(features).squeeze()
+    if t.ndim != 4:
+        raise ValueError(f'features must be (F, W, H, D), got {tuple(t.shape)}')
+    return t.to(device=device, dtype=torch.float16).contiguous()
+
+
+def sample_features3d(feat_vol, rel_coords, mode='nearest'):
+    """infer.py:48-72.  feat_vol ([M,] F, W, H, D); rel_coords ([M,] C, A, 3) in [-1, 1], volume dim
+    order.  Returns ([M,] C, A, F) on the device, fp32.  Unlike the reference it does not mutate `rel_coords`."""
+    lib = _lib.require_device()
+    dev = feat_vol.device if isinstance(feat_vol, torch.Tensor) and feat_vol.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    fv = torch.as_tensor(feat_vol)
+    if fv.ndim == 4:
+        fv = fv[None]
+    rc = torch.as_tensor(rel_coords)
+    while rc.ndim < 4:
+        rc = rc[None]
+    if rc.shape[0] != fv.shape[0]:
+        rc = rc.expand(fv.shape[0], -1, -1, -1)
+    m, c, a, _ = rc.shape
+    out = torch.empty((m, c, a, fv.shape[1]), dtype=torch.float32, device=dev)
+    for i in range(m):
+        f = fv[i]
+        is_half = f.dtype == torch.float16
+        f = f.to(dev, torch.float16 if is_half else torch.float32).contiguous()
+        rel = rc[i].reshape(-1, 3).to(dev, torch.float32).contiguous()
+        _lib.check(lib.vittf_sample_features(_lib.ptr(f), int(is_half), f.shape[0], f.shape[1], f.shape[2], f.shape[3],
+                                             _lib.ptr(rel), rel.shape[0], _lib.SAMPLE_MODES[mode], _lib.ptr(out[i]),
+                                             _lib.stream_ptr()), 'vittf_sample_features')
+    return out
+
+
+def compute_similarities(volume, features, annotations, bilateral_solver=False, device=None):
+    """predict_ntf.py:24-101 (bilateral_solver=False).  volume: (W, H, D) array/tensor (only its shape is
+    used); features: (F, W', H', D'); annotations: {name: (n, 3) voxel coords}.
+    Returns {name: uint8 CPU tensor (W//2, H//2, D//2)}; None when there is nothing to query
+    (predict_ntf.py:51-55).  Classes with zero annotations are skipped."""
+    if bilateral_solver:
+        raise NotImplementedError('bilateral solver post-process is outside the round-1 hot path (SURVEY.md 8f-1)')
+    if len(annotations) == 0:
+        return None
+    names = [k for k, v in annotations.items() if torch.as_tensor(v).shape[0] > 0]
+    if not names:
+        return None
+    lib = _lib.require_device()
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    feat = _device_features(features, dev)
+    f, n0, n1, n2 = feat.shape
+    in_dims = tuple(int(s) for s in tuple(volume.shape)[-3:])
+    sim_shape = tuple(d // 2 for d in in_dims)
+
+    coords = torch.cat([torch.as_tensor(annotations[k]).reshape(-1, 3) for k in names])
+    # rel = (abs + 0.5) / extent * 2 - 1 in fp32, exactly the reference expression (predict_ntf.py:56)
+    ext = torch.tensor([list(in_dims)], dtype=torch.float32)
+    rel = ((coords.float() + 0.5) / ext * 2.0 - 1.0).to(dev).contiguous()
+    a_total = rel.shape[0]
+    qf = torch.empty((a_total, f), dtype=torch.float32, device=dev)
+    _lib.check(lib.vittf_sample_features(_lib.ptr(feat), 1, f, n0, n1, n2, _lib.ptr(rel), a_total,
+                                         _lib.SAMPLE_MODES['bilinear'], _lib.ptr(qf), _lib.stream_ptr()),
+               'vittf_sample_features')
+
+    counts = [int(torch.as_tensor(annotations[k]).reshape(-1, 3).shape[0]) for k in names]
+    starts = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+    big = int(len(annotations) == 1 and counts[0] > 1024)      # predict_ntf.py:62
+    nclass = len(names)
+    ws_bytes = lib.vittf_similarity_workspace_bytes(nclass, n0 * n1 * n2)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = torch.empty((nclass, *sim_shape), dtype=torch.uint8, device=dev)
+    _lib.check(lib.vittf_similarity(_lib.ptr(feat), f, n0, n1, n2, _lib.ptr(qf),
+                                    starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big,
+                                    sim_shape[0], sim_shape[1], sim_shape[2], _lib.ptr(out), _lib.ptr(ws), ws_bytes,
+                                    _lib.stream_ptr()), 'vittf_similarity')
+    host = out.cpu()
+    return {k: host[i] for i, k in enumerate(names)}
+
+
+def assign_labels(similarities, thresholds=CT_ORG_THRESHOLDS, device=None):
+    """predict_ntf.py:203-215: list/dict of uint8 class maps (annotation order) -> uint8 label volume (numpy)."""
+    lib = _lib.require_device()
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    maps = list(similarities.values()) if isinstance(similarities, dict) else list(similarities)
+    maps = maps[:len(thresholds)]                       # zip() with the 5 CT-ORG names, predict_ntf.py:211
+    sims = torch.stack([torch.as_tensor(m).to(torch.uint8) for m in maps]).to(dev).contiguous()
+    n = sims[0].numel()
+    thr = (C.c_int32 * len(maps))(*[int(t * 255) for t in thresholds[:len(maps)]])
+    labels = torch.empty(sims.shape[1:], dtype=torch.uint8, device=dev)
+    _lib.check(lib.vittf_assign_labels(_lib.ptr(sims), len(maps), n, thr, _lib.ptr(labels), _lib.stream_ptr()),
+               'vittf_assign_labels')
+    return labels.cpu().numpy()

@@ -1,0 +1,153 @@
+"""Weights of the DINO ViT in the upstream state-dict layout: local loading, a seeded synthetic
+recipe, and the host-side preprocessing the HIP engine needs (channel folding, position embedding).
+
+The reference fetches the model over the network (``torch.hub.load('facebookresearch/dino:main',
+'dino_vits8')``, infer.py:42-43).  Here weights come from a LOCAL state-dict file (same key names as the
+DINO checkpoints: ``cls_token``, ``pos_embed``, ``patch_embed.proj.*``, ``blocks.{i}.norm1|attn.qkv|
+attn.proj|norm2|mlp.fc1|mlp.fc2.*``, ``norm.*``) or from the seeded synthetic recipe below when no
+checkpoint is available (benchmarks, tests).
+"""
+import math
+import os
+
+import torch
+import torch.nn.functional as F
+
+# name: (embed_dim, depth, heads, patch)   -- hub entries dino_<name>
+ARCHS = {
+    'vits8': (384, 12, 6, 8),
+    'vits16': (384, 12, 6, 16),
+    'vitb8': (768, 12, 12, 8),
+    'vitb16': (768, 12, 12, 16),
+}
+# file names torch.hub would have cached for these entries
+HUB_FILES = {
+    'vits8': 'dino_deitsmall8_pretrain.pth',
+    'vits16': 'dino_deitsmall16_pretrain.pth',
+    'vitb8': 'dino_vitbase8_pretrain.pth',
+    'vitb16': 'dino_vitbase16_pretrain.pth',
+}
+IN_MEAN = (0.485, 0.456, 0.406)   # infer.py:39
+IN_STD = (0.229, 0.224, 0.225)    # infer.py:40
+
+
+def arch_of(arch):
+    if isinstance(arch, str):
+        if arch not in ARCHS:
+            raise ValueError(f'unknown DINO arch {arch!r}; known: {sorted(ARCHS)}')
+        return ARCHS[arch]
+    dim, depth, heads, patch = arch
+    return int(dim), int(depth), int(heads), int(patch)
+
+
+def synthetic_state_dict(arch='vits8', seed=0, stored_grid=28):
+    """Seeded random weights with the DINO key layout.
+
+    Not an initialisation for training: the scales are chosen so that a forward pass looks like a trained
+    ViT numerically (unit-gain linears, attention logits with a std of a few units so the softmax is
+    peaked, non-trivial biases and LayerNorm affine terms) -- this keeps parity tests sensitive to
+    ordering / bias / masking mistakes and gives realistic data for benchmarking.
+    """
+    dim, depth, heads, patch = arch_of(arch)
+    g = torch.Generator().manual_seed(seed)
+
+    def rnd(*shape, std=1.0):
+        return torch.randn(*shape, generator=g) * std
+
+    sd = {
+        'cls_token': rnd(1, 1, dim, std=0.5),
+        'pos_embed': rnd(1, stored_grid * stored_grid + 1, dim, std=0.5),
+        'patch_embed.proj.weight': rnd(dim, 3, patch, patch, std=1.0 / math.sqrt(3 * patch * patch) * 3.0),
+        'patch_embed.proj.bias': rnd(dim, std=0.1),
+        'norm.weight': 1.0 + rnd(dim, std=0.1),
+        'norm.bias': rnd(dim, std=0.1),
+    }
+    for i in range(depth):
+        p = f'blocks.{i}.'
+        sd[p + 'norm1.weight'] = 1.0 + rnd(dim, std=0.1)
+        sd[p + 'norm1.bias'] = rnd(dim, std=0.1)
+        sd[p + 'attn.qkv.weight'] = rnd(3 * dim, dim, std=1.3 / math.sqrt(dim))
+        sd[p + 'attn.qkv.bias'] = rnd(3 * dim, std=0.1)
+        sd[p + 'attn.proj.weight'] = rnd(dim, dim, std=1.0 / math.sqrt(dim))
+        sd[p + 'attn.proj.bias'] = rnd(dim, std=0.1)
+        sd[p + 'norm2.weight'] = 1.0 + rnd(dim, std=0.1)
+        sd[p + 'norm2.bias'] = rnd(dim, std=0.1)
+        sd[p + 'mlp.fc1.weight'] = rnd(4 * dim, dim, std=1.0 / math.sqrt(dim))
+        sd[p + 'mlp.fc1.bias'] = rnd(4 * dim, std=0.1)
+        sd[p + 'mlp.fc2.weight'] = rnd(dim, 4 * dim, std=1.0 / math.sqrt(4 * dim))
+        sd[p + 'mlp.fc2.bias'] = rnd(dim, std=0.1)
+    return sd
+
+
+def load_state_dict_file(path):
+    """Load a DINO checkpoint from a local file; accepts bare backbones and teacher/student wrappers."""
+    sd = torch.load(path, map_location='cpu', weights_only=True)
+    for key in ('teacher', 'student', 'state_dict', 'model'):
+        if isinstance(sd, dict) and key in sd and isinstance(sd[key], dict):
+            sd = sd[key]
+            break
+    out = {}
+    for k, v in sd.items():
+        for prefix in ('module.', 'backbone.'):
+            if k.startswith(prefix):
+                k = k[len(prefix):]
+        if k.startswith('head.'):
+            continue
+        out[k] = v.float()
+    return out
+
+
+def find_local_checkpoint(name):
+    """Where a previously downloaded hub checkpoint would be; None if absent.  Never touches the network."""
+    env = os.environ.get('VITTF_WEIGHTS')
+    if env:
+        return env if os.path.exists(env) else None
+    hub = os.environ.get('TORCH_HOME', os.path.join(os.path.expanduser('~'), '.cache', 'torch'))
+    cand = os.path.join(hub, 'hub', 'checkpoints', HUB_FILES.get(name, ''))
+    return cand if os.path.isfile(cand) else None
+
+
+def state_dict_checksum(sd):
+    """Order-independent float64 checksum used by golden fixtures to detect generator drift."""
+    tot = 0.0
+    for k in sorted(sd):
+        t = sd[k].double()
+        tot += float((t * torch.arange(1, t.numel() + 1, dtype=torch.float64).reshape(t.shape).remainder(7.0)).sum())
+    return tot
+
+
+def fold_patch_embed(weight, bias):
+    """Fold the 3-channel conv applied to a grey image replicated over 3 ImageNet-normalised channels
+    into a single-channel conv acting on the [0, 1] grey value:
+
+        sum_c W[d,c,i,j] * (x - mean_c) / std_c + b[d]
+      = sum_ij (sum_c W[d,c,i,j] / std_c) * x_ij + (b[d] - sum_c mean_c / std_c * sum_ij W[d,c,i,j])
+
+    (infer.py:39-40, 154-155 + upstream PatchEmbed).  Returns (w_t [P*P][D], b [D]) fp32, folded in fp64.
+    """
+    w = weight.double()
+    mean = torch.tensor(IN_MEAN, dtype=torch.float64).view(1, 3, 1, 1)
+    std = torch.tensor(IN_STD, dtype=torch.float64).view(1, 3, 1, 1)
+    w1 = (w / std).sum(1)                                  # (D, P, P)
+    b1 = bias.double() - (w * mean / std).sum((1, 2, 3))
+    d = w.shape[0]
+    return w1.reshape(d, -1).t().contiguous().float(), b1.float()
+
+
+def interpolate_pos_embed(pos_embed, rows, cols, patch):
+    """Position embedding for a rows x cols pixel image, upstream form: bicubic,
+    ``scale_factor=((r0 + 0.1) / sqrt(N), (c0 + 0.1) / sqrt(N))``; identity for the stored square grid.
+    Runs once per image size on the host (it depends on the weights only).  Returns (1, 1 + r0*c0, D)."""
+    n_stored = pos_embed.shape[1] - 1
+    r0, c0 = rows // patch, cols // patch
+    if r0 * c0 == n_stored and rows == cols:
+        return pos_embed
+    dim = pos_embed.shape[-1]
+    g = int(math.sqrt(n_stored))
+    grid = pos_embed[:, 1:].reshape(1, g, g, dim).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid.float(), scale_factor=((r0 + 0.1) / math.sqrt(n_stored), (c0 + 0.1) / math.sqrt(n_stored)),
+                         mode='bicubic')
+    if grid.shape[-2] != r0 or grid.shape[-1] != c0:
+        raise ValueError(f'position-embedding grid {tuple(grid.shape[-2:])} != token grid {(r0, c0)}')
+    grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
+    return torch.cat((pos_embed[:, :1].float(), grid), dim=1)
