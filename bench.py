@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the vit-tf hot path on MI355X: slices/sec of the ViT-S/8 feature-volume extraction (+ the
+16-query similarity step), BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic volume that is already resident in HBM:
+every axis-aligned slice through ViT-S/8 (seeded synthetic weights, bf16 MFMA operands), slice-axis pooling,
+the fp16 z+y+x sum (with one RCCL all-gather per axis when N > 1), then a 16-query similarity volume and the
+label volume.  N = 1 runs BASELINE.json configs[1] (256^3 volume, 768 slices of 512 x 512); N > 1 runs
+configs[2] (512^3 CT-like volume, 1536 slices sharded over the ranks).  value = slices pushed through the
+ViT by all ranks / wall time of the K timed steps (max over ranks).
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (durations from HIP events recorded on the
+launch stream inside the timed region, algorithmic FLOPs from SURVEY.md 8d) and "cpu_baseline" (the oracle's
+CPU fp32 restatement of the same ViT on the host cores, rank 0 at N = 1, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import vit_tf_amd as vt   # noqa: E402
+
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0}     # dense MFMA peak, MI355X_MICROARCH.md
+FOS = 64
+
+
+def vit_flops(n_tokens, dim, depth, patch):
+    """Algorithmic FLOPs per slice: (attention, linear layers, patch embed)."""
+    attn = (depth - 1) * 4 * n_tokens * n_tokens * dim
+    lin = (depth - 1) * 24 * n_tokens * dim * dim + 2 * n_tokens * dim * dim
+    pe = 2 * (n_tokens - 1) * 3 * patch * patch * dim
+    return attn, lin, pe
+
+
+def make_workload(name):
+    """(volume fp16, label uint8, description) -- seeded, generated on the host before timing."""
+    if name == '256':
+        vol, label = vt.synthetic_volume('torus_filled', 256, 0.1, 0)
+        return vol, label, '256^3 synthetic torus volume (noise 0.1, seed 0), ViT-S/8, fos 64: 768 slices of 512x512 ' \
+                           '(N=4097) + 16-query similarity -> BASELINE configs[1]'
+    if name == '512':
+        vol, label = vt.ct_like_volume(512, 0)
+        return vol, label, '512^3 CT-like synthetic volume (seed 0), ViT-S/8, fos 64: 1536 slices of 512x512 (N=4097) ' \
+                           'sharded over the ranks + RCCL all-gather + 16-query similarity -> BASELINE configs[2]'
+    if name == '64':
+        vol, label = vt.synthetic_volume('torus_filled', 64, 0.1, 0)
+        return vol, label, '64^3 synthetic torus volume, ViT-S/8, fos 64: 192 slices of 512x512 (N=4097) -> BASELINE configs[0]'
+    raise SystemExit(f'unknown workload {name}')
+
+
+def query_voxels(label, n=16):
+    g = torch.Generator().manual_seed(0)
+    idx = (label > 0).nonzero()
+    pick = torch.randperm(idx.shape[0], generator=g)[:n]
+    return {'ntf1': idx[pick]}
+
+
+def cpu_baseline(sd, vol, n_slices, im_sz):
+    """The oracle (CPU restatement of the reference path) on the host cores: batch-1 slice loop, fp32."""
+    from oracle import dino_vit, feature_volume as ofv
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = dino_vit.build_vit('vits8', sd)
+    imgs = ofv.normalized_slices(vol.float(), 'z')
+    pick = [imgs.shape[0] // 2 + i for i in range(n_slices + 1)]
+    times = []
+    with torch.no_grad():
+        for i, s in enumerate(pick):
+            t0 = time.perf_counter()
+            x = torch.nn.functional.interpolate(imgs[s:s + 1], size=(im_sz[0], im_sz[1]), mode='nearest')
+            ofv.k_tokens(model, x).half()
+            if i > 0:
+                times.append(time.perf_counter() - t0)
+    return {'value': round(len(times) / sum(times), 4), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{len(times)} z-slices of the same volume at {im_sz[0]}x{im_sz[1]} (N=4097), batch 1, fp32 torch CPU, '
+                      f'after 1 warm-up slice; the oracle runs the K projection of block 12 only, like the GPU path'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', type=str, default=None, choices=['64', '256', '512'])
+    ap.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'fp16'])
+    ap.add_argument('--engine-batch', type=int, default=32)
+    ap.add_argument('--cpu-slices', type=int, default=5, help='slices timed for the CPU baseline (0 = skip)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        torch.distributed.init_process_group('nccl', device_id=dev)
+    barrier = (lambda: torch.distributed.barrier()) if world > 1 else (lambda: None)
+
+    wl = args.workload or ('256' if world == 1 else '512')
+    vol, label, desc = make_workload(wl)
+    sd = vt.synthetic_state_dict('vits8', 0)
+    model = vt.HipViT(sd, 'vits8', args.dtype, device=dev)
+    dvol = vt.DeviceVolume(vol, dev)                     # the input is resident in HBM before the timed region
+    ann = query_voxels(label)
+    im_sz, feat_out = vt.sizing(dvol.shape, FOS, 8)
+    n_tokens = (im_sz[0] // 8) * (im_sz[1] // 8) + 1
+    total_slices = sum(dvol.shape)
+    my_slices = 0
+    for sl in range(3):
+        w0, nw, _ = vt.extract.shard_windows(feat_out[sl], rank, world)
+        if nw:
+            my_slices += vt.extract.window_bounds(w0 + nw - 1, dvol.shape[sl], feat_out[sl])[1] - \
+                vt.extract.window_bounds(w0, dvol.shape[sl], feat_out[sl])[0]
+
+    def step():
+        feats = vt.feature_volume(None, model, FOS, 'all', args.engine_batch, dvol=dvol)
+        sims = vt.compute_similarities(vol, feats, ann)
+        return feats, vt.assign_labels(sims)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    vt._lib.profiler_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        feats, labels = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = vt._lib.profiler_collect()
+    vt._lib.profiler_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # similarity leg alone (outside the timed region): Mvoxel-sim/s = Nvox * A / time
+    n_rep = 5
+    torch.cuda.synchronize()
+    ts = time.perf_counter()
+    for _ in range(n_rep):
+        vt.compute_similarities(vol, feats, ann)
+    torch.cuda.synchronize()
+    sim_ms = (time.perf_counter() - ts) / n_rep * 1e3
+    nvox = feat_out[0] * feat_out[1] * feat_out[2]
+
+    attn_f, lin_f, pe_f = vit_flops(n_tokens, 384, 12, 8)
+    slices_done = my_slices * args.steps
+    flops = {'attention': attn_f * slices_done, 'gemm': lin_f * slices_done}
+    dom = max(('attention', 'gemm'), key=lambda k: prof[k][0])
+    dom_ms, dom_launches = prof[dom]
+    achieved = flops[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[args.dtype]
+    roofline = {
+        'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+        'traffic': None,
+        'kernel': {'attention': f'attn_kernel<{args.dtype}>', 'gemm': f'gemm_kernel<{args.dtype}, *>'}[dom],
+        'launches': int(dom_launches), 'avg_launch_ms': round(dom_ms / max(1, dom_launches), 4),
+        'flop_per_launch': flops[dom] / max(1, dom_launches),
+        'kernel_ms_rank0': {k: round(v[0], 2) for k, v in prof.items()},
+        'whole_vit_tflops': round((attn_f + lin_f + pe_f) * slices_done / (sum(v[0] for v in prof.values()) * 1e-3) / 1e12, 2)
+        if sum(v[0] for v in prof.values()) > 0 else 0.0,
+    }
+
+    if rank == 0:
+        out = {
+            'metric': 'slices/sec (ViT-S/8, feature volume + 16-query similarity)', 'value': round(args.steps * total_slices / elapsed, 2),
+            'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
+            'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': desc, 'volume': list(dvol.shape), 'slices_per_step': total_slices,
+                       'image': [im_sz[0], im_sz[1]], 'tokens': n_tokens, 'feature_volume': [384, *feat_out],
+                       'engine_batch': args.engine_batch, 'weights': 'seeded synthetic ViT-S/8 (seed 0)',
+                       'parallelism': f'slices sharded over {world} rank(s), one all-gather per axis' if world > 1 else 'single GPU'},
+            'roofline': roofline,
+            'similarity': {'ms': round(sim_ms, 3), 'queries': 16, 'mvoxel_sim_per_s': round(nvox * 16 / 1e6 / (sim_ms * 1e-3), 1),
+                           'mvoxel_per_s': round(nvox / 1e6 / (sim_ms * 1e-3), 1)},
+        }
+        if world == 1 and args.cpu_slices > 0:
+            out['cpu_baseline'] = cpu_baseline(sd, vol, args.cpu_slices, im_sz)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -122,6 +122,18 @@ int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit_weights* w
                          const vittf_slice_view* view, int32_t slice0, int32_t batch, int32_t qkv_part,
                          uint16_t* k_out, void* ws, size_t ws_bytes, void* stream);
 
+/* Optional timing of the launches inside vittf_vit_k_features, by kernel class, with HIP events recorded on
+ * the caller's stream (what bench.py's roofline leg reads).  Process-global, off by default, not thread-safe:
+ * the one exception to "no global mutable state".  enable(1) clears earlier records and starts recording,
+ * enable(0) stops; collect() waits for the recorded events and returns, per class, the summed launch
+ * durations in ms and the launch counts (arrays of VITTF_KERNEL_CLASSES entries, [host]). */
+typedef enum vittf_kernel_class {
+  VITTF_KERNEL_PATCH_EMBED = 0, VITTF_KERNEL_LAYERNORM = 1, VITTF_KERNEL_GEMM = 2, VITTF_KERNEL_ATTENTION = 3,
+  VITTF_KERNEL_CLASSES = 4
+} vittf_kernel_class;
+int vittf_profiler_enable(int32_t on);
+int vittf_profiler_collect(double* ms_per_class, int64_t* launches_per_class);
+
 /* ------------------------------------------------------------------------------------------
  * Individual kernels, exported so that each one is parity-tested on its own (tests/).
  * Row counts: activations are [rows][cols] row-major; `rows` need not be tile aligned.
@@ -160,8 +172,8 @@ int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, i
 
 /* Average-pool the slice axis of the token-major K features of ONE axis and scatter them, feature-major,
  * into a pooled slab:  for window i in [win0, win0 + nwin):
- *     slices [floor(i*S/n_out), ceil((i+1)*S/n_out))  (adaptive rule), fp32 sum in slice order, / count,
- *     rounded to fp16;  written to dst[d*dst_stride_d + (i - win0)*dst_stride_win + r*dst_stride_row + c*dst_stride_col]
+ *     slices [floor(i*S/n_out), ceil((i+1)*S/n_out))  (adaptive rule); running sum in slice order kept in
+ *     fp16 (one rounding per add, as the CPU AdaptiveAvgPool3d does for half tensors), then fp16(sum / count);  written to dst[d*dst_stride_d + (i - win0)*dst_stride_win + r*dst_stride_row + c*dst_stride_col]
  * k_slices holds slices [k_slice0, k_slice0 + k_nslices) of the axis as [slice][f0][f1][D] fp16; every
  * slice a requested window touches must be inside that range.  n_out == S gives the un-pooled layout. */
 int vittf_pool_slices(const uint16_t* k_slices, int32_t k_slice0, int32_t k_nslices, int32_t total_slices,

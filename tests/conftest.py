@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope='session')
+def gpu():
+    """Skip-free guard for -m gpu tests: they must run on a GPU box with the library built."""
+    import torch
+    import vit_tf_amd as vt
+    assert torch.cuda.is_available(), 'gpu-marked test started without a GPU'
+    lib = vt._lib.load()
+    assert lib.vittf_device_count() >= 1, 'no gfx950 device'
+    return torch.device('cuda', 0)

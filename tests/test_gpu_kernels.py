@@ -1,0 +1,338 @@
+"""GPU: each libvittf kernel, called through the C ABI, against an fp64 / oracle restatement of the op it
+replaces.  Tolerances are stated per test; integer / byte / fp16-pooling work is bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import vit_tf_amd as vt
+from vit_tf_amd import _lib
+from oracle import dino_vit, feature_volume as ofv, similarity as osim
+from helpers import load_golden, rel_fro, max_abs, TINY_ARCH
+
+pytestmark = pytest.mark.gpu
+
+TDT = {'bf16': torch.bfloat16, 'fp16': torch.float16}
+EPS = {'bf16': 2.0 ** -8, 'fp16': 2.0 ** -11}      # half-ulp relative rounding error of the 16-bit type
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows,d', [(1, 128), (5, 384), (1001, 384), (130, 768)])
+def test_layernorm(gpu, dt, rows, d):
+    lib = _lib.load()
+    g = gen(rows + d)
+    x = torch.randn(rows, d, generator=g) * 3.0 + torch.randn(rows, 1, generator=g) * 5.0
+    w = 1.0 + 0.1 * torch.randn(d, generator=g)
+    b = 0.1 * torch.randn(d, generator=g)
+    ref = F.layer_norm(x.double(), (d,), w.double(), b.double(), eps=1e-6)
+    xd, wd, bd = x.to(gpu), w.to(gpu), b.to(gpu)
+    y = torch.zeros(rows, d, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_layernorm(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), rows, d, 1e-6, _lib.DTYPES[dt],
+                                   _lib.stream_ptr()))
+    got = y.float().cpu().double()
+    # fp32 statistics + one rounding to the 16-bit type
+    assert ((got - ref).abs() <= EPS[dt] * ref.abs() * 1.01 + 2e-5).all()
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def _gemm_inputs(rows, n, k, dt, seed):
+    g = gen(seed)
+    a = (torch.randn(rows, k, generator=g)).to(TDT[dt])
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(TDT[dt])
+    bias = 0.2 * torch.randn(n, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    return a, w, bias, ref
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows,n,k', [(1, 128, 64), (100, 128, 128), (128, 384, 384), (300, 1152, 384),
+                                      (257, 384, 1536), (8194, 1536, 384)])
+def test_gemm_bias_and_gelu(gpu, dt, rows, n, k):
+    lib = _lib.load()
+    a, w, bias, ref = _gemm_inputs(rows, n, k, dt, rows + n + k)
+    ad, wd, bd = a.to(gpu), w.to(gpu), bias.to(gpu)
+    for epi, refv in ((_lib.EPI_BIAS, ref), (_lib.EPI_BIAS_GELU, F.gelu(ref))):
+        out = torch.full((rows + 3, n), 7.0, dtype=TDT[dt], device=gpu)       # 3 guard rows
+        _lib.check(lib.vittf_gemm(_lib.ptr(ad), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), rows, n, k, epi, 0,
+                                  _lib.DTYPES[dt], _lib.stream_ptr()))
+        got = out.float().cpu().double()
+        assert (got[rows:] == 7.0).all(), 'wrote past the last row'
+        # fp32 accumulation (error ~ 1e-6 * sqrt(k)) + one rounding of the output
+        assert ((got[:rows] - refv).abs() <= EPS[dt] * refv.abs() * 1.01 + 3e-5 * k ** 0.5).all()
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows,n,k', [(3, 128, 64), (515, 384, 384), (200, 384, 1536)])
+def test_gemm_residual(gpu, dt, rows, n, k):
+    lib = _lib.load()
+    a, w, bias, ref = _gemm_inputs(rows, n, k, dt, rows * 3 + n)
+    x0 = torch.randn(rows + 2, n, generator=gen(5)) * 4.0
+    xd = x0.to(gpu)
+    _lib.check(lib.vittf_gemm(_lib.ptr(a.to(gpu)), _lib.ptr(w.to(gpu)), _lib.ptr(bias.to(gpu)), _lib.ptr(xd), rows, n, k,
+                              _lib.EPI_BIAS_RESIDUAL, 0, _lib.DTYPES[dt], _lib.stream_ptr()))
+    got = xd.cpu().double()
+    assert torch.equal(got[rows:], x0[rows:].double())
+    assert ((got[:rows] - (x0[:rows].double() + ref)).abs() <= 1e-5 * k ** 0.5 + 1e-6 * ref.abs()).all()
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+def test_gemm_kfeat_drops_cls_rows(gpu, dt):
+    lib = _lib.load()
+    tokens, batch, n, k = 17, 9, 128, 128
+    rows = tokens * batch
+    a, w, bias, ref = _gemm_inputs(rows, n, k, dt, 99)
+    out = torch.full((batch * (tokens - 1) + 1, n), 7.0, dtype=torch.float16, device=gpu)
+    _lib.check(lib.vittf_gemm(_lib.ptr(a.to(gpu)), _lib.ptr(w.to(gpu)), _lib.ptr(bias.to(gpu)), _lib.ptr(out), rows, n, k,
+                              _lib.EPI_KFEAT, tokens, _lib.DTYPES[dt], _lib.stream_ptr()))
+    got = out.float().cpu().double()
+    want = ref.view(batch, tokens, n)[:, 1:].reshape(-1, n)
+    assert (got[-1] == 7.0).all()
+    assert ((got[:-1] - want).abs() <= EPS['fp16'] * want.abs() * 1.01 + 3e-5 * k ** 0.5).all()
+
+
+def test_gemm_rejects_bad_shapes(gpu):
+    lib = _lib.load()
+    t = torch.zeros(256, 256, dtype=torch.float16, device=gpu)
+    f = torch.zeros(256, dtype=torch.float32, device=gpu)
+    for n, k in ((100, 64), (128, 60)):
+        assert lib.vittf_gemm(_lib.ptr(t), _lib.ptr(t), _lib.ptr(f), _lib.ptr(t), 4, n, k, 0, 0, 1, _lib.stream_ptr()) == -1
+    assert lib.vittf_gemm(None, _lib.ptr(t), _lib.ptr(f), _lib.ptr(t), 4, 128, 64, 0, 0, 1, _lib.stream_ptr()) == -1
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, batch, tokens, heads):
+    d = heads * 64
+    x = qkv.double().view(batch, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0], x[1], x[2]
+    att = (q @ k.transpose(-2, -1)) * 0.125
+    return (att.softmax(-1) @ v).transpose(1, 2).reshape(batch * tokens, d)
+
+
+def _run_attn(gpu, qkv, batch, tokens, heads, dt):
+    lib = _lib.load()
+    qd = qkv.to(gpu)
+    out = torch.full((batch * tokens + 2, heads * 64), 7.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().double()
+    assert (got[batch * tokens:] == 7.0).all(), 'wrote past the last row'
+    return got[:batch * tokens]
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('batch,tokens,heads', [(1, 1, 2), (2, 17, 2), (1, 64, 2), (3, 65, 2), (1, 128, 6), (2, 129, 2),
+                                                (1, 200, 6), (2, 577, 2), (1, 1025, 2)])
+def test_attention_small(gpu, dt, batch, tokens, heads):
+    g = gen(batch * 1000 + tokens)
+    qkv = torch.randn(batch * tokens, 3 * heads * 64, generator=g)
+    qkv[:, :2 * heads * 64] *= 1.6          # logits with a std of ~2.5: a peaked softmax
+    qkv = qkv.to(TDT[dt])
+    ref = _attn_ref(qkv, batch, tokens, heads)
+    got = _run_attn(gpu, qkv, batch, tokens, heads, dt)
+    vmax = float(qkv[:, 2 * heads * 64:].float().abs().max())
+    # P is rounded to the 16-bit type before the second product, the output once more
+    assert rel_fro(got, ref) <= 3 * EPS[dt]
+    assert max_abs(got, ref) <= 6 * EPS[dt] * vmax
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+def test_attention_rescale_branch(gpu, dt):
+    """Force the running maximum to jump in a late key tile (the online-softmax rescale path) and to sit in the
+    ragged last tile; a uniform-random check never exercises that."""
+    batch, tokens, heads = 1, 333, 2
+    g = gen(4)
+    qkv = torch.randn(batch * tokens, 3 * heads * 64, generator=g) * 0.5
+    q = qkv[:, :128].view(tokens, 2, 64)
+    k = qkv[:, 128:256].view(tokens, 2, 64)
+    for key_row in (5, 200, 332):                       # first tile, a middle tile, the ragged last tile
+        k[key_row, 0] = q[7 + key_row % 50, 0] * 12.0   # one query row suddenly matches this key strongly
+    qkv = qkv.to(TDT[dt])
+    ref = _attn_ref(qkv, batch, tokens, heads)
+    got = _run_attn(gpu, qkv, batch, tokens, heads, dt)
+    assert torch.isfinite(got).all()
+    assert rel_fro(got, ref) <= 3 * EPS[dt]
+    assert max_abs(got, ref) <= 6 * EPS[dt] * float(qkv[:, 256:].float().abs().max())
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+def test_attention_full_size(gpu, dt):
+    """N = 4097 (512^2 image, P = 8), 6 heads: the headline shape; reference in fp64 on the GPU via torch ops."""
+    batch, tokens, heads = 2, 4097, 6
+    g = gen(77)
+    qkv = torch.randn(batch * tokens, 3 * heads * 64, generator=g)
+    qkv[:, :2 * heads * 64] *= 1.5
+    qkv = qkv.to(TDT[dt])
+    lib = _lib.load()
+    qd = qkv.to(gpu)
+    out = torch.zeros(batch * tokens, heads * 64, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], _lib.stream_ptr()))
+    x = qd.double().view(batch, tokens, 3, heads, 64)
+    err2, ref2, mx = 0.0, 0.0, 0.0
+    for b in range(batch):
+        for h in range(heads):
+            q, k, v = x[b, :, 0, h], x[b, :, 1, h], x[b, :, 2, h]
+            r = ((q @ k.t()) * 0.125).softmax(-1) @ v
+            d = out[b * tokens:(b + 1) * tokens, h * 64:(h + 1) * 64].double() - r
+            err2 += float((d * d).sum()); ref2 += float((r * r).sum()); mx = max(mx, float(d.abs().max()))
+    assert (err2 / ref2) ** 0.5 <= 3 * EPS[dt]
+    assert mx <= 6 * EPS[dt] * float(qkv[:, 2 * heads * 64:].float().abs().max())
+
+
+# ------------------------------------------------------------------------------------------ front end
+def test_volume_minmax(gpu):
+    lib = _lib.load()
+    for n in (1, 7, 1000, 64 * 64 * 64 + 3):
+        v = torch.randn(n, generator=gen(n)) * 100
+        vd = v.to(gpu)
+        out = torch.zeros(2, device=gpu)
+        ws = torch.empty(lib.vittf_minmax_workspace_bytes(), dtype=torch.uint8, device=gpu)
+        _lib.check(lib.vittf_volume_minmax(_lib.ptr(vd), n, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        assert out.cpu().tolist() == [float(v.min()), float(v.max())]
+
+
+@pytest.mark.parametrize('axis', ['z', 'y', 'x'])
+@pytest.mark.parametrize('shape,im_sz', [((24, 16, 32), (24, 16, 32)), ((20, 12, 28), (16, 8, 16)), ((10, 10, 10), (32, 32, 32))])
+def test_patch_embed_matches_prepare_tokens(gpu, axis, shape, im_sz):
+    """gather + min-max + ImageNet normalise + nearest resize + conv + CLS + pos-embed, in exact fp32."""
+    sd = vt.synthetic_state_dict(TINY_ARCH, 3)
+    oracle = dino_vit.build_vit(TINY_ARCH, sd)
+    vol = (torch.rand(shape, generator=gen(9)) * 300 - 100).half().float()
+    imgs = ofv.normalized_slices(vol, axis)
+    rows, cols = ofv.axis_image_size(im_sz, axis)
+    with torch.no_grad():
+        ref = oracle.prepare_tokens(F.interpolate(imgs, size=(rows, cols), mode='nearest'))
+    model = vt.HipViT(sd, TINY_ARCH, 'fp16')
+    dvol = vt.DeviceVolume(vol, gpu)
+    view = dvol.view(axis, im_sz)
+    pos, _, _ = model.pos_for(rows, cols)
+    n_slices = imgs.shape[0]
+    out = torch.zeros(n_slices, ref.shape[1], 128, device=gpu)
+    _lib.check(model.lib.vittf_patch_embed(C.byref(model.cfg), C.byref(model.weights), C.byref(pos), C.byref(view), 0,
+                                           n_slices, _lib.ptr(out), _lib.stream_ptr()))
+    got = out.cpu()
+    assert got.shape == ref.shape
+    assert torch.allclose(got, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------ pooling / axis sum
+@pytest.mark.parametrize('axis', ['z', 'y', 'x'])
+@pytest.mark.parametrize('S,n_out,f0,f1', [(32, 4, 3, 2), (10, 4, 4, 4), (7, 7, 2, 70), (130, 130, 1, 3), (16, 1, 5, 5)])
+def test_pool_slices_bit_exact(gpu, axis, S, n_out, f0, f1):
+    lib = _lib.load()
+    d = 128
+    k = (torch.randn(S, f0, f1, d, generator=gen(S + f1)) * 4).half()
+    sl, (a, b) = vt.AXIS_DIMS[axis]
+    order = [None] * 3
+    order[sl], order[a], order[b] = 0, 1, 2
+    full = k.permute(3, *order).contiguous()                      # reference layout (D, ...S at the axis...)
+    size = list(full.shape[1:])
+    size[sl] = n_out
+    ref = F.adaptive_avg_pool3d(full, tuple(size))                # fp16 in / out, like infer.py:203,329
+    n = [0, 0, 0]
+    n[sl], n[a], n[b] = n_out, f0, f1
+    shape, strides = vt.extract._slab_shape_strides(axis, d, n, n_out)
+    dst = torch.zeros(shape, dtype=torch.float16, device=gpu)
+    kd = k.to(gpu)
+    _lib.check(lib.vittf_pool_slices(_lib.ptr(kd), 0, S, S, n_out, 0, n_out, f0, f1, d, _lib.ptr(dst), *strides,
+                                     _lib.stream_ptr()))
+    assert torch.equal(dst.cpu(), ref)
+    # a sub-range of windows from a sub-range of resident slices gives the same bits (what a rank computes)
+    if n_out >= 2:
+        w0, nw = n_out // 2, n_out - n_out // 2
+        s0 = vt.extract.window_bounds(w0, S, n_out)[0]
+        shape2, strides2 = vt.extract._slab_shape_strides(axis, d, n, nw)
+        dst2 = torch.zeros(shape2, dtype=torch.float16, device=gpu)
+        ksub = k[s0:].contiguous().to(gpu)
+        _lib.check(lib.vittf_pool_slices(_lib.ptr(ksub), s0, S - s0, S, n_out, w0, nw, f0, f1, d, _lib.ptr(dst2),
+                                         *strides2, _lib.stream_ptr()))
+        assert torch.equal(dst2.cpu(), ref.narrow(1 + sl, w0, nw))
+    # windows whose slices are not resident are refused
+    if S > 1:
+        assert lib.vittf_pool_slices(_lib.ptr(kd), 1, S - 1, S, n_out, 0, n_out, f0, f1, d, _lib.ptr(dst), *strides,
+                                     _lib.stream_ptr()) == -1
+
+
+@pytest.mark.parametrize('world', [1, 2, 3])
+def test_assemble_sum_bit_exact(gpu, world):
+    lib = _lib.load()
+    d, n = 128, (5, 4, 7)
+    g = gen(world)
+    vols = {ax: (torch.randn(d, *n, generator=g) * 8).half() for ax in 'zyx'}
+    ref = ((0.0 + vols['z']) + vols['y']) + vols['x']            # fp16 adds, z -> y -> x (infer.py:330-332)
+    chunks, gathered = [0, 0, 0], {}
+    for ax in 'zyx':
+        sl = vt.AXIS_DIMS[ax][0]
+        c = -(-n[sl] // world)
+        chunks[sl] = c
+        pad = list(vols[ax].shape)
+        pad[1 + sl] = c * world
+        padded = torch.zeros(pad, dtype=torch.float16)
+        padded.narrow(1 + sl, 0, n[sl]).copy_(vols[ax])
+        gathered[ax] = torch.stack(padded.split(c, dim=1 + sl)).contiguous().to(gpu)     # [world, D, ...chunk...]
+    out = torch.zeros(d, *n, dtype=torch.float16, device=gpu)
+    carr = (C.c_int32 * 3)(*chunks)
+    _lib.check(lib.vittf_assemble_sum(_lib.ptr(gathered['z']), _lib.ptr(gathered['y']), _lib.ptr(gathered['x']), world,
+                                      carr, d, n[0], n[1], n[2], _lib.ptr(out), _lib.stream_ptr()))
+    assert torch.equal(out.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------ similarity side
+def test_sample_features_golden(gpu, golden_dir):
+    g = load_golden(golden_dir, 'sampling.npz')
+    feat, rel = torch.from_numpy(g['feat']), torch.from_numpy(g['rel'])
+    for src in (feat, feat.half()):                               # fp32 and fp16 storage (values are fp16-exact)
+        for mode in ('nearest', 'bilinear'):
+            got = vt.sample_features3d(src.to(gpu), rel.clone(), mode)
+            assert got.shape == (1, 1, 16, 32)
+            ref = torch.from_numpy(g[mode])
+            assert torch.allclose(got[0, 0].cpu(), ref, rtol=0, atol=1e-6)
+            assert (got[0, 0].cpu() == ref).float().mean() > 0.99     # same operation order: (almost) always identical
+
+
+def test_similarity_golden(gpu, golden_dir):
+    g = load_golden(golden_dir, 'similarity.npz')
+    feat = torch.from_numpy(g['feat'])
+    vol = np.zeros(tuple(int(x) for x in g['vol_shape']), dtype=np.float32)
+    ann = {'ntf1': torch.from_numpy(g['ann_ntf1']), 'ntf2': torch.from_numpy(g['ann_ntf2'])}
+    got = vt.compute_similarities(vol, feat, ann)
+    for k in ann:
+        assert got[k].dtype == torch.uint8 and tuple(got[k].shape) == g[f'sim_{k}'].shape
+        assert np.array_equal(got[k].numpy(), g[f'sim_{k}']), f'{k}: {(got[k].numpy() != g[f"sim_{k}"]).sum()} voxels differ'
+    assert np.array_equal(vt.assign_labels(got), g['labels'])
+    big = vt.compute_similarities(vol, feat, {'ntf1': torch.from_numpy(g['ann_big'])})
+    diff = big['ntf1'].numpy().astype(int) - g['sim_big'].astype(int)
+    # 1030 fp32 dot products summed in a different order than torch's einsum: allow isolated 1-LSB flips
+    assert (diff != 0).sum() <= 2 and np.abs(diff[np.abs(diff) < 128]).max(initial=0) <= 1
+
+
+def test_similarity_many_classes_and_chunks(gpu):
+    """17 + 16 + 1 + 40 annotations in 4 classes: chunks of 16 straddle class boundaries; vs the oracle."""
+    g = gen(21)
+    feat = F.normalize(torch.randn(64, 6, 7, 8, generator=g), dim=0)
+    feat = F.normalize(feat + 0.7 * feat[:, 1:2, 2:3, 3:4], dim=0).half().float()
+    shape = (12, 14, 16)
+    ann = {f'c{i}': torch.stack([torch.randint(0, s, (n,), generator=g) for s in shape], 1)
+           for i, n in enumerate((17, 16, 1, 40))}
+    got = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann)
+    ref = osim.similarity_maps(shape, feat, ann)
+    for k in ann:
+        diff = got[k].numpy().astype(int) - ref[k].numpy().astype(int)
+        assert (diff != 0).mean() <= 0.01, k
+    labels = vt.assign_labels(got)
+    assert labels.dtype == np.uint8 and labels.shape == tuple(s // 2 for s in shape)
+    assert np.array_equal(labels, osim.assign_labels([got[k] for k in ann]))     # bit-exact on the same maps
+
+
+def test_labels_bit_exact_random(gpu):
+    g = gen(8)
+    sims = [torch.randint(0, 256, (9, 10, 11), generator=g, dtype=torch.uint8) for _ in range(5)]
+    assert np.array_equal(vt.assign_labels(sims), osim.assign_labels(sims))
+    sims7 = sims + sims[:2]                                        # more maps than thresholds: extra ones are ignored
+    assert np.array_equal(vt.assign_labels(sims7), osim.assign_labels(sims7))

@@ -1,0 +1,182 @@
+"""CPU: host-side logic of the product and the C-ABI surface (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import vit_tf_amd as vt
+from vit_tf_amd import _lib
+from oracle import dino_vit, feature_volume as ofv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'vittf.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(vittf_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 17
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/vittf.h but not exported by libvittf.so'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.vittf_abi_version() == 1
+    assert lib.vittf_status_string(-2) == b'workspace too small'
+
+
+def test_workspace_query_and_argument_validation_need_no_gpu():
+    lib = _lib.load()
+    cfg = _lib.VitConfig(384, 12, 6, 8, _lib.BF16, 1e-6)
+    one = lib.vittf_vit_workspace_bytes(ctypes.byref(cfg), 1, 4097)
+    many = lib.vittf_vit_workspace_bytes(ctypes.byref(cfg), 32, 4097)
+    # fp32 residual + LN out + qkv + attention out = 4 + 2 + 6 + 2 bytes per token-feature
+    assert one >= 4097 * 384 * 14 and 31 * one < many <= 32 * one
+    bad = _lib.VitConfig(384, 12, 5, 8, _lib.BF16, 1e-6)           # heads * 64 != D
+    assert lib.vittf_vit_workspace_bytes(ctypes.byref(bad), 1, 4097) == 0
+    assert lib.vittf_gemm(None, None, None, None, 1, 128, 64, 0, 0, 0, None) == -1
+    assert lib.vittf_similarity_workspace_bytes(2, 64 ** 3) >= 2 * 64 ** 3 * 4
+
+
+def test_product_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(vt.VittfError):
+        vt.HipViT(vt.synthetic_state_dict((128, 1, 2, 8), 0), (128, 1, 2, 8))
+    with pytest.raises(vt.VittfError):
+        vt.compute_similarities(np.zeros((4, 4, 4)), torch.zeros(8, 2, 2, 2), {'a': torch.zeros(2, 3)})
+    r = subprocess.run([sys.executable, 'infer.py', '--data-path', 'x.npy', '--cpu'], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 1 and 'no CPU path' in r.stdout
+
+
+def test_sizing_rule_matches_reference_configs():
+    assert vt.sizing((512, 512, 512), 64, 8) == ((512,) * 3, (64,) * 3)
+    assert vt.sizing((256, 256, 256), 64, 8) == ((512,) * 3, (64,) * 3)
+    assert vt.sizing((64, 64, 64), 64, 8) == ((512,) * 3, (64,) * 3)
+    assert vt.sizing((512, 512, 512), 128, 8) == ((1024,) * 3, (128,) * 3)
+    for shape, fos in (((200, 256, 312), 64), ((10, 10, 10), 4), ((20, 12, 28), 2)):
+        assert vt.sizing(shape, fos, 8) == ofv.sizing(shape, fos, 8)
+
+
+def test_shard_windows_cover_everything_once():
+    for n_out in (1, 3, 8, 50, 64, 78):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                first, cnt, chunk = vt.extract.shard_windows(n_out, r, world)
+                assert cnt <= chunk and chunk * world >= n_out
+                seen += list(range(first, first + cnt))
+            assert seen == list(range(n_out))
+
+
+def test_folded_patch_embed_equals_three_channel_conv():
+    sd = vt.synthetic_state_dict('vits8', 1)
+    w, b = sd['patch_embed.proj.weight'], sd['patch_embed.proj.bias']
+    w_t, b1 = vt.fold_patch_embed(w, b)
+    assert w_t.shape == (64, 384) and b1.shape == (384,)
+    x = torch.rand(5, 1, 8, 8, dtype=torch.float64)
+    mean = torch.tensor(vt.weights.IN_MEAN, dtype=torch.float64).view(1, 3, 1, 1)
+    std = torch.tensor(vt.weights.IN_STD, dtype=torch.float64).view(1, 3, 1, 1)
+    ref = torch.nn.functional.conv2d((x.expand(-1, 3, -1, -1) - mean) / std, w.double(), b.double())[:, :, 0, 0]
+    got = x.reshape(5, 64) @ w_t.double() + b1.double()
+    assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_pos_embed_interpolation_is_the_upstream_form():
+    sd = vt.synthetic_state_dict((128, 1, 2, 8), 2)
+    for rows, cols in ((512, 512), (24, 16), (64, 256), (224, 224)):
+        mine = vt.interpolate_pos_embed(sd['pos_embed'], rows, cols, 8)
+        ref = dino_vit.interpolate_pos_embed(sd['pos_embed'], (rows // 8) * (cols // 8), rows, cols, 8)
+        assert torch.equal(mine, ref)
+    # the scale-factor form differs from a plain size= resize: make sure we did not "simplify" it
+    g = sd['pos_embed'][:, 1:].reshape(1, 28, 28, 128).permute(0, 3, 1, 2)
+    plain = torch.nn.functional.interpolate(g, size=(64, 64), mode='bicubic').permute(0, 2, 3, 1).reshape(1, -1, 128)
+    assert (vt.interpolate_pos_embed(sd['pos_embed'], 512, 512, 8)[:, 1:] - plain).abs().max() > 1e-3
+
+
+def test_state_dict_roundtrip_and_checksum(tmp_path):
+    sd = vt.synthetic_state_dict((128, 2, 2, 8), 4)
+    assert vt.weights.state_dict_checksum(sd) == vt.weights.state_dict_checksum(vt.synthetic_state_dict((128, 2, 2, 8), 4))
+    assert vt.weights.state_dict_checksum(sd) != vt.weights.state_dict_checksum(vt.synthetic_state_dict((128, 2, 2, 8), 5))
+    torch.save({'teacher': {'backbone.' + k: v for k, v in sd.items()} | {'head.mlp.weight': torch.zeros(2)}}, tmp_path / 'ck.pth')
+    back = vt.load_state_dict_file(tmp_path / 'ck.pth')
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    dino_vit.build_vit((128, 2, 2, 8), back)        # loads strictly into the oracle's module tree (DINO key names)
+
+
+def test_reference_shaped_helpers():
+    import infer
+    t = torch.zeros(4, 5)
+    assert infer.make_3d(t).shape == (1, 4, 5) and infer.make_5d(t).shape == (1, 1, 1, 4, 5)
+    with pytest.raises(Exception):
+        infer.make_nd(torch.zeros(2, 2, 2), 2)
+    x = torch.tensor([1.0, 3.0, 5.0])
+    assert torch.equal(infer.norm_minmax(x), torch.tensor([0.0, 0.5, 1.0]))
+    assert infer.in_mean == [0.485, 0.456, 0.406] and infer.in_std == [0.229, 0.224, 0.225]
+
+    class A:
+        dino_model = None; dino2_model = None
+    a = A()
+    assert infer.load_model(a)[0::2] == ('vits8', 8) and a.model == 'vits8'
+    a = A(); a.dino_model = 'vitb16'
+    assert infer.load_model(a)[2] == 16
+    a = A(); a.dino_model = 'vits8'; a.dino2_model = 'vits14'
+    with pytest.raises(SystemExit) as e:
+        infer.load_model(a)
+    assert e.value.code == 1
+
+
+def test_output_path_contract(tmp_path):
+    import infer
+
+    class A:
+        pass
+    a = A(); a.data_path = str(tmp_path / 'vol.npy'); a.cache_path = None; a.model = 'vits8'; a.slice_along = 'all'
+    a.feature_output_size = 64; a.overwrite = False
+    p = infer.handle_output_path(a)
+    assert p.name == 'vol_vits8_all_features64.npy'
+    p.write_bytes(b'x')
+    a.cache_path = None
+    with pytest.raises(SystemExit) as e:
+        infer.handle_output_path(a)
+    assert e.value.code == 1
+    a.cache_path = None; a.overwrite = True
+    assert infer.handle_output_path(a) == p
+    # file formats of load_data (infer.py:212-237)
+    v = torch.rand(3, 4, 5).half()
+    np.save(tmp_path / 'a.npy', v.numpy()); np.save(tmp_path / 'b.npy', {'vol': v.numpy()})
+    torch.save(v, tmp_path / 'c.pt'); torch.save({'vol': v}, tmp_path / 'd.pt')
+    for name, dt in (('a.npy', torch.float32), ('b.npy', torch.float32), ('c.pt', torch.float16), ('d.pt', torch.float16)):
+        got = infer.load_data(tmp_path / name)
+        assert got.dtype == dt and torch.equal(got.float(), v.float())
+    with pytest.raises(SystemExit):
+        infer.load_data(tmp_path / 'missing.npy')
+    infer.save_features({'k': v}, tmp_path / 'f.npy')
+    assert np.load(tmp_path / 'f.npy', allow_pickle=True)[()]['k'].dtype == np.float16
+
+
+def test_evaluate_similarities_entry(tmp_path):
+    import json
+    import evaluate_similarities as ev
+    labels = np.zeros((8, 8, 8), np.uint8); labels[2:6, 2:6, 2:6] = 3
+    np.save(tmp_path / 'labels.npy', labels)
+    pred = np.zeros((4, 4, 4), np.uint8); pred[1:3, 1:3, 1:3] = 1
+    np.save(tmp_path / 'predictions.npy', {'ntf0': pred})
+    json.dump({'ntf0': {'time': 1.5, 'num_annotations': 3}}, open(tmp_path / 'metadata.json', 'w'))
+    res = ev.evaluate(tmp_path, tmp_path / 'labels.npy', ['lung'])
+    assert res['lung']['accuracy'] == 1.0 and res['lung']['iou'] == [1.0, 1.0] and res['lung']['num_annotations'] == 3
+
+
+def test_samplers():
+    from vit_tf_amd.samplers import sample_uniform, sample_surface, sample_both
+    _, lab = vt.synthetic_volume('sphere_filled', 32)
+    torch.manual_seed(0)
+    u = sample_uniform(lab, 20)
+    assert u.shape == (20, 3) and bool(lab[u[:, 0], u[:, 1], u[:, 2]].all()) and len({tuple(r) for r in u.tolist()}) == 20
+    s = sample_surface(lab.numpy(), 20)
+    assert s.shape == (20, 3) and bool(lab[s[:, 0], s[:, 1], s[:, 2]].all())
+    assert sample_both(lab.numpy(), 10).shape == (10, 3)

@@ -1,0 +1,30 @@
+#!/usr/bin/env bash
+# Runs on the GPU box (via gpurun): GPU parity tests, smoke, a short bench and a rocprofv3 kernel trace.
+# A step that times out or is killed stops the whole script (no further GPU work after a hang).
+set -u
+mkdir -p gpurun_out
+OUT=gpurun_out
+step() {  # step <name> <timeout-seconds> <cmd...>
+  local name=$1 tmo=$2; shift 2
+  echo "=== $name" | tee -a $OUT/summary.log
+  timeout -k 10 "$tmo" "$@" > "$OUT/$name.log" 2>&1
+  local rc=$?
+  echo "rc=$rc" | tee -a $OUT/summary.log
+  tail -n 25 "$OUT/$name.log"
+  if [ $rc -ge 124 ]; then echo "step $name timed out / was killed: stopping" | tee -a $OUT/summary.log; exit $rc; fi
+  return 0
+}
+: > $OUT/summary.log
+for s in "$@"; do
+  case $s in
+    kernels)  step test_kernels 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider ;;
+    pipeline) step test_pipeline 900 python -m pytest tests/test_gpu_pipeline.py -q -m gpu -s -p no:cacheprovider ;;
+    smoke)    step smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    bench)    step bench 900 python bench.py --steps 2 --warmup 1 ;;
+    bench64)  step bench64 600 python bench.py --steps 1 --warmup 1 --workload 64 --cpu-slices 0 ;;
+    prof)     cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
+              step rocprof 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 1 --warmup 1 --workload 64 --cpu-slices 0 ;;
+    *) echo "unknown step $s" ;;
+  esac
+done
+echo "=== done" | tee -a $OUT/summary.log

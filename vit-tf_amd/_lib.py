@@ -53,6 +53,8 @@ SIGNATURES = {
     'vittf_vit_workspace_bytes': (_sz, [_P(VitConfig), _i32, _i32]),
     'vittf_vit_k_features': (C.c_int, [_P(VitConfig), _P(VitWeights), _P(PosEmbed), _P(SliceView), _i32, _i32, _i32,
                                        _vp, _vp, _sz, _vp]),
+    'vittf_profiler_enable': (C.c_int, [_i32]),
+    'vittf_profiler_collect': (C.c_int, [_P(C.c_double), _P(_i64)]),
     'vittf_patch_embed': (C.c_int, [_P(VitConfig), _P(VitWeights), _P(PosEmbed), _P(SliceView), _i32, _i32, _vp, _vp]),
     'vittf_layernorm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, C.c_float, _i32, _vp]),
     'vittf_gemm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -88,6 +90,21 @@ def load():
         raise VittfError('libvittf.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib
+
+
+KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention')
+
+
+def profiler_enable(on=True):
+    check(load().vittf_profiler_enable(int(bool(on))), 'vittf_profiler_enable')
+
+
+def profiler_collect():
+    """{class: (total ms, launches)} of the vittf_vit_k_features launches recorded since profiler_enable(True)."""
+    ms = (C.c_double * len(KERNEL_CLASSES))()
+    n = (C.c_int64 * len(KERNEL_CLASSES))()
+    check(load().vittf_profiler_collect(ms, n), 'vittf_profiler_collect')
+    return {k: (ms[i], n[i]) for i, k in enumerate(KERNEL_CLASSES)}
 
 
 def check(rc, what=''):

@@ -13,7 +13,31 @@
 // Everything is enqueued on the caller's stream; nothing synchronises with the host.
 #include "vittf_common.h"
 
+#include <vector>
+
 namespace {
+// ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
+// Process-global and off by default; the only mutable state in the library.  Not thread-safe.
+struct ProfRec { hipEvent_t a, b; int cls; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope {
+  ProfRec r; hipStream_t st; bool on;
+  ProfScope(int cls, void* stream) : st((hipStream_t)stream), on(g_prof_on) {
+    if (on) { r.cls = cls; r.a = prof_event(); r.b = prof_event(); (void)hipEventRecord(r.a, st); }
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof_recs.push_back(r); } }
+};
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
@@ -90,34 +114,63 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   void* O = base + lay.o;
   void* G = QKV;  // [rows][4D] hidden, aliases QKV|O (both dead while the MLP runs)
 
-  int rc = vittf_patch_embed(cfg, w, pos, view, slice0, batch, X, stream);
+  int rc;
+  { ProfScope ps(VITTF_KERNEL_PATCH_EMBED, stream); rc = vittf_patch_embed(cfg, w, pos, view, slice0, batch, X, stream); }
   if (rc) return rc;
   const size_t esz = 2;
   for (int l = 0; l < L; ++l) {
     const char* qkv_w = (const char*)w->qkv_w + (size_t)l * 3 * d * d * esz;
-    rc = vittf_layernorm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
+    { ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
+      rc = vittf_layernorm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream); }
     if (rc) return rc;
     if (l == L - 1) {
       // hooked tensor, one third only: rows [part*D, (part+1)*D) of qkv.weight / qkv.bias  (infer.py:189-201)
+      ProfScope ps(VITTF_KERNEL_GEMM, stream);
       return vittf_gemm(H, qkv_w + (size_t)qkv_part * d * d * esz, w->qkv_b + (size_t)l * 3 * d + (size_t)qkv_part * d,
                         k_out, rows, d, d,
                         VITTF_EPI_KFEAT, tokens, dt, stream);
     }
-    rc = vittf_gemm(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, VITTF_EPI_BIAS, 0, dt, stream);
+    { ProfScope ps(VITTF_KERNEL_GEMM, stream);
+      rc = vittf_gemm(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, VITTF_EPI_BIAS, 0, dt, stream); }
     if (rc) return rc;
-    rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, stream);
+    { ProfScope ps(VITTF_KERNEL_ATTENTION, stream);
+      rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, stream); }
     if (rc) return rc;
-    rc = vittf_gemm(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d, d,
-                    VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream);
+    { ProfScope ps(VITTF_KERNEL_GEMM, stream);
+      rc = vittf_gemm(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d, d,
+                      VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
     if (rc) return rc;
-    rc = vittf_layernorm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
+    { ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
+      rc = vittf_layernorm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream); }
     if (rc) return rc;
-    rc = vittf_gemm(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows,
-                    4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream);
+    { ProfScope ps(VITTF_KERNEL_GEMM, stream);
+      rc = vittf_gemm(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows,
+                      4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream); }
     if (rc) return rc;
-    rc = vittf_gemm(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
-                    4 * d, VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream);
+    { ProfScope ps(VITTF_KERNEL_GEMM, stream);
+      rc = vittf_gemm(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
+                      4 * d, VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
     if (rc) return rc;
+  }
+  return VITTF_OK;
+}
+
+extern "C" int vittf_profiler_enable(int32_t on) {
+  for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+  g_prof_recs.clear();
+  g_prof_on = on != 0;
+  return VITTF_OK;
+}
+
+extern "C" int vittf_profiler_collect(double* ms_per_class, int64_t* launches_per_class) {
+  if (!ms_per_class || !launches_per_class) return VITTF_ERR_INVALID_ARG;
+  for (int i = 0; i < VITTF_KERNEL_CLASSES; ++i) { ms_per_class[i] = 0.0; launches_per_class[i] = 0; }
+  for (auto& r : g_prof_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return VITTF_ERR_LAUNCH;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return VITTF_ERR_LAUNCH;
+    ms_per_class[r.cls] += ms;
+    launches_per_class[r.cls] += 1;
   }
   return VITTF_OK;
 }

@@ -4,12 +4,16 @@
 // Replaces k[:, 1:].view(S, f0, f1, D).permute(0, 3, 1, 2).permute(permute_out) (infer.py:201-203),
 // torch.nn.AdaptiveAvgPool3d(feat_out_sz) (infer.py:329; in-plane it is the identity because the token grid
 // already equals feat_out_sz, only the slice axis is reduced) and the running fp16 sum of infer.py:330-332.
+// Rounding follows the reference's CPU path bit for bit: the CPU kernel of AdaptiveAvgPool3d accumulates a
+// window in the tensor dtype (fp16, one rounding per add, slice order) and rounds sum / count once more.
 // HBM-bound byte shuffling: 16-byte loads along the feature dim, an LDS transpose, 128-byte store runs.
 #include "vittf_common.h"
 
 namespace {
 
 constexpr int PT = 64;  // tile: 64 items of the fast output dim x 64 features
+
+__device__ __forceinline__ float f16_round(float v) { return f16bits_to_f32(f32_to_f16bits(v)); }
 
 struct PoolArgs {
   const unsigned short* k;
@@ -59,8 +63,9 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
         const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[2 * j] += f16bits_to_f32((unsigned short)(u[j] & 0xffff));
-          acc[2 * j + 1] += f16bits_to_f32((unsigned short)(u[j] >> 16));
+          // the CPU AdaptiveAvgPool3d keeps its running sum in the tensor's own type: round to fp16 per add
+          acc[2 * j] = f16_round(acc[2 * j] + f16bits_to_f32((unsigned short)(u[j] & 0xffff)));
+          acc[2 * j + 1] = f16_round(acc[2 * j + 1] + f16bits_to_f32((unsigned short)(u[j] >> 16)));
         }
       }
       const float cnt = (float)(hi - lo);
@@ -83,8 +88,6 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
     }
   }
 }
-
-__device__ __forceinline__ float f16_round(float v) { return f16bits_to_f32(f32_to_f16bits(v)); }
 
 __global__ __launch_bounds__(256) void assemble_sum_kernel(const unsigned short* __restrict__ gz,
                                                            const unsigned short* __restrict__ gy,

@@ -84,10 +84,36 @@ def k_slices(model, dvol, axis, im_sizes, s0, s1, engine_batch=DEFAULT_ENGINE_BA
     return out
 
 
-def _pool_into(lib, kbuf, k_s0, n_slices_total, n_out, win0, nwin, f0, f1, d, dst, strides):
-    sd, sw, sr, sc = strides
-    _lib.check(lib.vittf_pool_slices(_lib.ptr(kbuf), k_s0, kbuf.shape[0], n_slices_total, n_out, win0, nwin, f0, f1, d,
-                                     _lib.ptr(dst), sd, sw, sr, sc, _lib.stream_ptr()), 'vittf_pool_slices')
+class HipOps:
+    """The device operations the sharding logic below is written against: all of them libvittf kernels.
+    (tests/ substitute a CPU stand-in built on the oracle to exercise the multi-rank logic under gloo;
+    the product never does.)"""
+
+    def volume(self, vol, model):
+        return DeviceVolume(vol, model.device)
+
+    def k_slices(self, model, dvol, axis, im_sizes, s0, s1, engine_batch, part):
+        return k_slices(model, dvol, axis, im_sizes, s0, s1, engine_batch, part)
+
+    def zeros(self, shape, model):
+        return torch.zeros(shape, dtype=torch.float16, device=model.device)
+
+    def pool(self, model, kbuf, k_s0, n_slices_total, n_out, win0, nwin, f0, f1, d, dst, strides):
+        sd, sw, sr, sc = strides
+        _lib.check(model.lib.vittf_pool_slices(_lib.ptr(kbuf), k_s0, kbuf.shape[0], n_slices_total, n_out, win0, nwin,
+                                               f0, f1, d, _lib.ptr(dst), sd, sw, sr, sc, _lib.stream_ptr()),
+                   'vittf_pool_slices')
+
+    def assemble_sum(self, model, gz, gy, gx, world, chunks, d, feat_out):
+        out = torch.empty((d, *feat_out), dtype=torch.float16, device=model.device)
+        carr = (C.c_int32 * 3)(*chunks)
+        _lib.check(model.lib.vittf_assemble_sum(_lib.ptr(gz), _lib.ptr(gy), _lib.ptr(gx), world, carr, d, feat_out[0],
+                                                feat_out[1], feat_out[2], _lib.ptr(out), _lib.stream_ptr()),
+                   'vittf_assemble_sum')
+        return out
+
+
+_HIP_OPS = HipOps()
 
 
 def _slab_shape_strides(axis, d, n, chunk):
@@ -100,11 +126,11 @@ def _slab_shape_strides(axis, d, n, chunk):
     return (d, *dims), (dims[0] * dims[1] * dims[2], st[sl], st[a], st[b])
 
 
-def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=DEFAULT_ENGINE_BATCH, part=1, group=None):
+def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=DEFAULT_ENGINE_BATCH, part=1, group=None,
+                  ops=_HIP_OPS):
     """Pooled (n_out windows along the slice dim) features of one axis, gathered over the process group.
 
     Returns (gathered [world, D, *slab_dims] fp16 device tensor, chunk)."""
-    lib = model.lib
     world = torch.distributed.get_world_size(group) if _dist_on(group) else 1
     rank = torch.distributed.get_rank(group) if world > 1 else 0
     sl, a, b, n_slices, f0, f1 = _axis_geometry(dvol.shape, im_sizes, axis, model.patch_size)
@@ -113,13 +139,13 @@ def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=DEFAULT_ENGIN
     n[sl], n[a], n[b] = n_out, f0, f1
     win0, nwin, chunk = shard_windows(n_out, rank, world)
     shape, strides = _slab_shape_strides(axis, d, n, chunk)
-    gathered = torch.zeros((world, *shape), dtype=torch.float16, device=model.device)
+    gathered = ops.zeros((world, *shape), model)
     slab = gathered[rank]
     if nwin > 0:
         s0 = window_bounds(win0, n_slices, n_out)[0]
         s1 = window_bounds(win0 + nwin - 1, n_slices, n_out)[1]
-        kbuf = k_slices(model, dvol, axis, im_sizes, s0, s1, engine_batch, part)
-        _pool_into(lib, kbuf, s0, n_slices, n_out, win0, nwin, f0, f1, d, slab, strides)
+        kbuf = ops.k_slices(model, dvol, axis, im_sizes, s0, s1, engine_batch, part)
+        ops.pool(model, kbuf, s0, n_slices, n_out, win0, nwin, f0, f1, d, slab, strides)
         del kbuf
     if world > 1:
         # one exchange step per axis: RCCL all-gather of the pooled slab (in place into `gathered`)
@@ -140,42 +166,38 @@ def assemble_axis(gathered, axis, n_total):
 
 
 def feature_volume(vol, model, feature_output_size=64, slice_along='all', engine_batch=DEFAULT_ENGINE_BATCH,
-                   part=1, group=None, dvol=None):
+                   part=1, group=None, dvol=None, ops=_HIP_OPS):
     """infer.py:314-333 on the GPU(s).  Returns the fp16 feature tensor on the device:
     'all' -> (D, W', H', D') = fp16(fp16(z + y) + x) of the pooled axes; 'x'|'y'|'z' -> un-pooled single axis."""
-    lib = model.lib
     if dvol is None:
-        dvol = DeviceVolume(vol, model.device)
+        dvol = ops.volume(vol, model)
     im_sz, feat_out = sizing(dvol.shape, feature_output_size, model.patch_size)
     if min(im_sz) <= 0:
         raise ValueError(f'feature_output_size {feature_output_size} gives an empty image size {im_sz}')
     if slice_along in AXIS_DIMS:
         sl = AXIS_DIMS[slice_along][0]
-        g, _ = axis_features(model, dvol, slice_along, im_sz, dvol.shape[sl], engine_batch, part, group)
+        g, _ = axis_features(model, dvol, slice_along, im_sz, dvol.shape[sl], engine_batch, part, group, ops)
         return assemble_axis(g, slice_along, dvol.shape[sl])
     if slice_along != 'all':
         raise Exception(f'Invalid argument for --slice-along: {slice_along}. Must be x,y,z or all')
     gathered, chunks = {}, [0, 0, 0]
     for ax in ('z', 'y', 'x'):
         sl = AXIS_DIMS[ax][0]
-        gathered[ax], chunks[sl] = axis_features(model, dvol, ax, im_sz, feat_out[sl], engine_batch, part, group)
+        gathered[ax], chunks[sl] = axis_features(model, dvol, ax, im_sz, feat_out[sl], engine_batch, part, group, ops)
     world = gathered['z'].shape[0]
-    out = torch.empty((model.embed_dim, *feat_out), dtype=torch.float16, device=model.device)
-    carr = (C.c_int32 * 3)(*chunks)
-    _lib.check(lib.vittf_assemble_sum(_lib.ptr(gathered['z']), _lib.ptr(gathered['y']), _lib.ptr(gathered['x']), world,
-                                      carr, model.embed_dim, feat_out[0], feat_out[1], feat_out[2], _lib.ptr(out),
-                                      _lib.stream_ptr()), 'vittf_assemble_sum')
-    return out
+    out = ops.assemble_sum(model, gathered['z'], gathered['y'], gathered['x'], world, chunks, model.embed_dim, feat_out)
+    return out.squeeze()        # the reference's running sum drops singleton dims (infer.py:332 v.squeeze())
 
 
-def pooled_axis(vol, model, axis, im_sizes, out_size, engine_batch=DEFAULT_ENGINE_BATCH, part=1, group=None, dvol=None):
+def pooled_axis(vol, model, axis, im_sizes, out_size, engine_batch=DEFAULT_ENGINE_BATCH, part=1, group=None, dvol=None,
+                ops=_HIP_OPS):
     """compute_qkv(..., pool_fn=AdaptiveAvgPool3d(out_size)) for one axis: (D, *out_size) fp16 on the device."""
     if dvol is None:
-        dvol = DeviceVolume(vol, model.device)
+        dvol = ops.volume(vol, model)
     sl, (a, b) = AXIS_DIMS[axis]
     p = model.patch_size
     if out_size[a] != im_sizes[a] // p or out_size[b] != im_sizes[b] // p:
         raise NotImplementedError('in-plane pooling: the HIP path pools the slice axis only (the token grid already '
                                   'equals feat_out_sz for every sizing infer.py produces, infer.py:317-319)')
-    g, _ = axis_features(model, dvol, axis, im_sizes, out_size[sl], engine_batch, part, group)
+    g, _ = axis_features(model, dvol, axis, im_sizes, out_size[sl], engine_batch, part, group, ops)
     return assemble_axis(g, axis, out_size[sl])
