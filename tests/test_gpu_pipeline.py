@@ -6,7 +6,7 @@ Floating-point tolerance.  BASELINE.json asks for "1e-3 relative on bf16 feature
 here is the relative Frobenius error of the feature tensor against the fp32 CPU path, and the bounds below are
 what each operand type achieves through the whole network (measured values are printed by the tests and
 recorded in DESIGN.md): fp16 operands (the reference's own GPU type, infer.py:309) meet 1e-3 on the pooled
-feature volume; bf16 operands are held to 8e-3.
+feature volume; bf16 operands measure 2.4e-3 .. 3.8e-3 and are held to 8e-3 (single slices) / 6e-3 (pooled volume).
 """
 import json
 import os
@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # relative Frobenius error bounds per operand type: (un-pooled single slice features, pooled + summed volume)
-TOL = {'fp16': (2e-3, 1e-3), 'bf16': (1.6e-2, 8e-3)}
+TOL = {'fp16': (1e-3, 1e-3), 'bf16': (8e-3, 6e-3)}
 
 
 @pytest.mark.parametrize('dt', ['fp16', 'bf16'])
