@@ -66,10 +66,23 @@ def query_voxels(label, n=16):
     return {'ntf1': idx[pick]}
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box exposes all
+    256 host CPUs to os.cpu_count() but grants a 16-CPU share; oversubscribing it makes torch 10x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get('VITTF_CPU_THREADS', '16'))))
+
+
 def cpu_baseline(sd, vol, n_slices, im_sz):
     """The oracle (CPU restatement of the reference path) on the host cores: batch-1 slice loop, fp32."""
     from oracle import dino_vit, feature_volume as ofv
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     model = dino_vit.build_vit('vits8', sd)
     imgs = ofv.normalized_slices(vol.float(), 'z')
