@@ -116,10 +116,15 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    local = local % max(1, torch.cuda.device_count())     # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('VITTF_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
     barrier = (lambda: torch.distributed.barrier()) if world > 1 else (lambda: None)
 
     wl = args.workload or ('256' if world == 1 else '512')
@@ -158,7 +163,7 @@ def main():
     prof = vt._lib.profiler_collect()
     vt._lib.profiler_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -203,10 +203,14 @@ def _init_distributed():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1:
         return 0, 1
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if not torch.distributed.is_initialized():
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        backend = os.environ.get('VITTF_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            torch.distributed.init_process_group(backend)
     return torch.distributed.get_rank(), world
 
 

@@ -211,3 +211,32 @@ def test_entry_points_end_to_end(gpu, tmp_path):
     assert {'mIoU', 'predict_time', 'fit_time', 'confusion_matrix'} <= set(metrics)
     r = run('predict_ntf.py', '--data', str(d), '--num-samples', '16', '--sampling-mode', 'uniform')
     assert r.returncode == 0 and 'Already inferred' in r.stdout
+
+
+def test_two_ranks_share_one_gpu_rehearsal(gpu, tmp_path):
+    """The multi-rank path end to end with the real kernels: 2 ranks (gloo rendezvous, both on cuda:0) shard the
+    slices of every axis, exchange pooled slabs, and must write the same bits as a single process.
+    (RCCL itself needs one GPU per rank; the driver's 8-GPU run uses backend 'nccl' on the same code path.)"""
+    env = dict(os.environ, PYTHONPATH=ROOT, VITTF_DIST_BACKEND='gloo')
+    vol, _ = vt.synthetic_volume('sphere_filled', 40, 0.2, 3)
+    np.save(tmp_path / 'v.npy', vol.numpy())
+    common = ['--data-path', str(tmp_path / 'v.npy'), '--feature-output-size', '5', '--synthetic-weights', '1']
+    r = subprocess.run([sys.executable, 'infer.py', *common, '--cache-path', str(tmp_path / 'one.npy')], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29611', 'infer.py', *common,
+                        '--cache-path', str(tmp_path / 'two.npy')], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    one = np.load(tmp_path / 'one.npy', allow_pickle=True)[()]['k']
+    two = np.load(tmp_path / 'two.npy', allow_pickle=True)[()]['k']
+    assert one.shape == (384, 5, 5, 5) and np.array_equal(one, two)
+    # and the benchmark's N > 1 leg (tiny workload) prints its one JSON line from rank 0
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29612', 'bench.py', '--gpus', '2', '--steps', '1',
+                        '--warmup', '0', '--workload', '64'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr + r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['roofline']['achieved'] > 0 and out['cpu_baseline'] is None

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Per-kernel microbenchmark on the headline shapes (batch 32 slices of N = 4097 tokens, ViT-S/8), timed with
+events on the launch stream; random data (zeros inflate MFMA clocks).  Usage: python tools/bench_kernels.py [what...]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import vit_tf_amd as vt   # noqa: E402
+from vit_tf_amd import _lib   # noqa: E402
+
+TDT = {'bf16': torch.bfloat16, 'fp16': torch.float16}
+
+
+def timeit(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    what = set(sys.argv[1:]) or {'attn', 'gemm', 'ln', 'sim'}
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    dt = os.environ.get('DT', 'bf16')
+    batch, tokens, heads, d = int(os.environ.get('BATCH', '32')), int(os.environ.get('TOKENS', '4097')), 6, 384
+    rows = batch * tokens
+    g = torch.Generator(device='cpu').manual_seed(0)
+    if 'attn' in what:
+        qkv = torch.randn(rows, 3 * d, generator=g)
+        qkv[:, :2 * d] *= 1.5
+        qkv = qkv.to(TDT[dt]).to(dev)
+        out = torch.empty(rows, d, dtype=TDT[dt], device=dev)
+        ms = timeit(lambda: _lib.check(lib.vittf_attention(_lib.ptr(qkv), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], _lib.stream_ptr())))
+        fl = batch * 4 * tokens * tokens * d
+        print(f'attention  batch {batch} N {tokens}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({fl / ms / 1e9 / 25:.1f} % of 2.5 PF)')
+    if 'gemm' in what:
+        for name, n, k, epi in (('qkv', 3 * d, d, 0), ('proj+res', d, d, 2), ('fc1+gelu', 4 * d, d, 1), ('fc2+res', d, 4 * d, 2), ('kfeat', d, d, 3)):
+            a = torch.randn(rows, k, generator=g).to(TDT[dt]).to(dev)
+            w = (torch.randn(n, k, generator=g) / k ** 0.5).to(TDT[dt]).to(dev)
+            bias = torch.randn(n, generator=g).to(dev)
+            o = torch.zeros(rows, n, dtype=torch.float32 if epi == 2 else TDT[dt], device=dev)
+            ms = timeit(lambda: _lib.check(lib.vittf_gemm(_lib.ptr(a), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(o), rows, n, k, epi, tokens, _lib.DTYPES[dt], _lib.stream_ptr())))
+            fl = 2 * rows * n * k
+            byts = rows * k * 2 + n * k * 2 + rows * n * (8 if epi == 2 else 2)
+            print(f'gemm {name:9s} [{rows}x{k}]x[{n}x{k}]^T: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s   {byts / ms / 1e6:.0f} GB/s algorithmic')
+    if 'ln' in what:
+        x = torch.randn(rows, d, generator=g).to(dev)
+        w = torch.ones(d, device=dev); b = torch.zeros(d, device=dev)
+        y = torch.empty(rows, d, dtype=TDT[dt], device=dev)
+        ms = timeit(lambda: _lib.check(lib.vittf_layernorm(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), rows, d, 1e-6, _lib.DTYPES[dt], _lib.stream_ptr())))
+        print(f'layernorm [{rows}x{d}]: {ms:.3f} ms  {rows * d * 6 / ms / 1e6:.0f} GB/s')
+    if 'sim' in what:
+        import numpy as np
+        feat = torch.randn(384, 64, 64, 64, generator=g).half().to(dev)
+        for na in (1, 16, 64):
+            ann = {'a': torch.randint(0, 256, (na, 3), generator=g)}
+            vol = np.zeros((256, 256, 256), np.float32)
+            ms = timeit(lambda: vt.compute_similarities(vol, feat, ann), reps=5, warm=2)
+            print(f'similarity 64^3x384, A={na}: {ms:.3f} ms end-to-end  ({feat.numel() * 2 / ms / 1e6:.0f} GB/s of feature bytes, {262144 * na / ms / 1e3:.0f} Mvoxel-sim/s)')
+
+
+if __name__ == '__main__':
+    main()

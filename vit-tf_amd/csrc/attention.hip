@@ -5,37 +5,149 @@
 //
 // Machine mapping (gfx950, wave64):
 //   * one 256-thread workgroup = 4 waves = 128 query rows of one (slice, head); each wave owns 32 query rows
-//   * K/V tiles of 64 keys are register-staged (global_load_dwordx4 issued before the tile's MFMAs, ds_write
-//     after them) into two LDS buffers, one barrier per tile
+//   * K/V tiles of 64 keys are register-staged (buffer_load_dwordx4 issued before the tile's MFMAs, ds_write
+//     after them) into two LDS buffers, one barrier per tile; the buffer descriptor's range check zero-fills rows
+//     past the end of the slice, the tile offset rides in the scalar offset, so the prefetch costs no VALU
 //   * scores are computed TRANSPOSED, S^T = K Q^T with v_mfma_f32_32x32x16 (K rows as the A operand, Q rows as
 //     the B operand, Q fragments live in registers for the whole kernel), so a lane owns one query column:
-//     the row maximum / row sum of the online softmax are in-lane reductions plus ONE exchange with lane^32
-//   * the S^T accumulator registers, converted pairwise to 16 bit, are directly the B operand of the second
-//     product O^T = V^T P^T (k order 16s + 8(j>>2) + 4h + (j&3)); the matching V^T A-fragments come from
+//     the row maximum / row sum of the online softmax are in-lane reductions plus ONE v_permlane32_swap
+//   * the S^T accumulator registers, converted pairwise to 16 bit (v_cvt_pk), are directly the B operand of the
+//     second product O^T = V^T P^T (k order 16s + 8(j>>2) + 4h + (j&3)); the matching V^T A-fragments come from
 //     ds_read_b64_tr_b16 transposed reads of a row-major V image (8-row x 32-col subtiles, conflict free)
 //   * the K image uses the tile_off() swizzle shared with the GEMM and is read with ds_read_b128
+//   * every LDS address is a per-lane base computed once + an immediate (the two buffers are two instantiations
+//     of the tile body): the kernel is VALU-bound at head dim 64 (PMC: VALU 75 % busy vs MFMA 38 %), so address
+//     arithmetic inside the loop is what was removed first
 //   * exp2 with the softmax scale folded into one FMA: p = exp2(s*c - m*c), c = log2(e)/8
-//   * token count need not be tile aligned (N = f0*f1 + 1): query/key rows past the end are clamped on load,
-//     the last key tile is masked to -inf, stores are guarded
+//   * token count need not be tile aligned (N = f0*f1 + 1): the last key tile is masked to -inf, query rows
+//     past the end are clamped on load and their stores are guarded
 //   * workgroups are remapped so that the q-tiles of one (slice, head) share an XCD's L2 (K/V re-reads)
 #include "vittf_common.h"
+
+#include <stdlib.h>
 
 namespace {
 
 constexpr int QT = 128;   // query rows per workgroup
 constexpr int KT = 64;    // keys per tile
 constexpr int KV_TILE_BYTES = KT * 64 * 2;  // 8 KB
+constexpr int BUF_BYTES = 2 * KV_TILE_BYTES; // K | V
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 // V image: [8 key groups][2 column halves] subtiles of 8 keys x 32 columns (512 B), chunk XOR by (key>>2)&3
 __device__ __forceinline__ int v_off(int key, int ch) {
   return 1024 * (key >> 3) + 512 * (ch >> 2) + 64 * (key & 7) + 16 * ((ch & 3) ^ ((key >> 2) & 3));
 }
 
-template <int DT>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const unsigned short* __restrict__ qkv,
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// One 64-key tile for this wave's 32 query rows.  BUF selects the LDS buffer at compile time so that every
+// ds_read offset is an immediate on one of six per-lane base registers.  LAST masks keys >= tokens.
+template <int DT, int BUF, bool LAST, int VAR>
+__device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, const char* ka2, const char* ka3,
+                                          const char* va0, const char* va1, const s16x8_t& q0, const s16x8_t& q1,
+                                          const s16x8_t& q2, const s16x8_t& q3, f32x16_t& o0, f32x16_t& o1,
+                                          f32x16_t& lacc, float& m_run, float& l_run, int t, int tokens, int h, float c) {
+  // Two 32-key halves, each carried from S^T to O^T before the next one starts: the score registers (16) and
+  // the P fragments (8) of one half are all that is live, which keeps the kernel at 4 waves per SIMD.
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    constexpr int kb = BUF * BUF_BYTES;
+    f32x16_t sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    sacc = mfma32<DT>(*reinterpret_cast<const s16x8_t*>(ka0 + kb + 4096 * kt), q0, sacc);
+    sacc = mfma32<DT>(*reinterpret_cast<const s16x8_t*>(ka1 + kb + 4096 * kt), q1, sacc);
+    sacc = mfma32<DT>(*reinterpret_cast<const s16x8_t*>(ka2 + kb + 4096 * kt), q2, sacc);
+    sacc = mfma32<DT>(*reinterpret_cast<const s16x8_t*>(ka3 + kb + 4096 * kt), q3, sacc);
+    if constexpr (LAST) {  // ragged last tile: keys >= tokens contribute nothing
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * KT + 32 * kt + acc_row(r, h);
+        if (key >= tokens) sacc[r] = -INFINITY;
+      }
+    }
+
+    // ---- online softmax (lane = one query column; 16 of the half's 32 keys are in this lane) ----
+    // v_max3 through asm: fmaxf() on MFMA outputs makes hipcc insert a canonicalising v_max per operand
+    float tmax = max3_f32(sacc[0], sacc[1], sacc[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) tmax = max3_f32(tmax, sacc[r], sacc[r + 1]);
+    tmax = max3_f32(tmax, sacc[15], sacc[15]);
+    float m_new;
+    {
+      const unsigned tb = __float_as_uint(tmax);
+      const auto sw = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);   // one of the two holds the other half
+      m_new = max3_f32(m_run, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float mc = m_new * c;
+    if (!__all(m_new == m_run)) {   // rare after the first tiles: rescale what was accumulated at the old maximum
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      if constexpr (VAR & 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+      }
+      m_run = m_new;
+    }
+    float psum0 = 0.f, psum1 = 0.f;
+    float p[16];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -mc));
+      p[r + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[r + 1], c, -mc));
+      if constexpr (!(VAR & 2)) { psum0 += p[r]; psum1 += p[r + 1]; }
+    }
+    if constexpr (!(VAR & 2)) l_run += psum0 + psum1;
+    s16x8_t pf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      u32x4_t u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = pack2_h16<DT>(p[8 * s2 + 2 * j], p[8 * s2 + 2 * j + 1]);
+      pf[s2] = __builtin_bit_cast(s16x8_t, u);
+    }
+
+    // ---- O^T += V^T P^T for these 32 keys ----
+    if constexpr (VAR & 2) {
+      // row sums on the matrix pipe (which has slack) instead of 16 VALU adds: ones[32][16] . P^T[16][32 q]
+      // puts sum_k P[q][k] -- over the keys of BOTH lane halves -- in every register of lacc
+      constexpr short one = DT == VITTF_BF16 ? (short)0x3F80 : (short)0x3C00;
+      const s16x8_t ones = {one, one, one, one, one, one, one, one};
+      lacc = mfma32<DT>(ones, pf[0], lacc);
+      lacc = mfma32<DT>(ones, pf[1], lacc);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int dvt = 0; dvt < 2; ++dvt) {
+        constexpr int vb = BUF * BUF_BYTES + KV_TILE_BYTES;
+        const int imm = vb + 4096 * kt + 2048 * s2 + 512 * dvt;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(va0 + imm));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(va1 + imm + 1024));
+        const s16x8_t vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (dvt == 0) o0 = mfma32<DT>(vf, pf[s2], o0);
+        else          o1 = mfma32<DT>(vf, pf[s2], o1);
+      }
+    }
+    if constexpr (!(VAR & 4)) __builtin_amdgcn_sched_barrier(0);   // keep the halves sequential: interleaving them costs 40 VGPRs and a wave per SIMD
+  }
+}
+
+template <int DT, int VAR>
+__global__ __launch_bounds__(256, (VAR & 2) ? 3 : 4) void attn_kernel(const unsigned short* __restrict__ qkv,
                                                       unsigned short* __restrict__ out, int tokens, int heads,
                                                       int q_tiles, int total, float c) {
-  __shared__ __attribute__((aligned(16))) char smem[2][2][KV_TILE_BYTES];  // [buffer][K | V]
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];  // [buffer][K | V]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -45,161 +157,119 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const unsigned short* __re
   const int bh = item / q_tiles;
   const int hd = bh % heads, b = bh / heads;
   const int dmodel = heads * 64;
-  const int64_t ld = 3 * (int64_t)dmodel;
+  const int ld = 3 * dmodel;                                   // elements per token row of qkv
   const unsigned short* base = qkv + (int64_t)b * tokens * ld;
-  const unsigned short* kbase = base + dmodel + hd * 64;
-  const unsigned short* vbase = base + 2 * dmodel + hd * 64;
+
+  // buffer descriptor over this slice's qkv rows: loads past the last token return 0 (no clamping VALU)
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((int64_t)tokens * ld * 2), 0x00020000);
 
   // ---- Q fragments (B operand): lane holds Q[row l31][16 s + 8 h .. +7] ----
   const int qrow = qt * QT + wave * 32 + l31;
   const int qrow_c = qrow < tokens ? qrow : tokens - 1;
-  s16x8_t qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-    qf[s] = *reinterpret_cast<const s16x8_t*>(base + (int64_t)qrow_c * ld + hd * 64 + 16 * s + 8 * h);
+  const unsigned short* qp = base + (int64_t)qrow_c * ld + hd * 64 + 8 * h;
+  s16x8_t q0 = *reinterpret_cast<const s16x8_t*>(qp);
+  s16x8_t q1 = *reinterpret_cast<const s16x8_t*>(qp + 16);
+  s16x8_t q2 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+  s16x8_t q3 = *reinterpret_cast<const s16x8_t*>(qp + 48);
 
-  // ---- staging assignment: 512 chunks of 16 B per tile, two per thread (rows r, r + 32; chunk tid & 7) ----
-  const int st_row = tid >> 3, st_ch = tid & 7;
-  uint4 kreg[2], vreg[2];
-  auto load_tile = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key = t * KT + st_row + 32 * i;
-      key = key < tokens ? key : tokens - 1;
-      kreg[i] = *reinterpret_cast<const uint4*>(kbase + (int64_t)key * ld + st_ch * 8);
-      vreg[i] = *reinterpret_cast<const uint4*>(vbase + (int64_t)key * ld + st_ch * 8);
-    }
-  };
-  auto write_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = st_row + 32 * i;
-      *reinterpret_cast<uint4*>(&smem[buf][0][tile_off(r, st_ch)]) = kreg[i];
-      *reinterpret_cast<uint4*>(&smem[buf][1][v_off(r, st_ch)]) = vreg[i];
-    }
-  };
+  // ---- staging: LDS-DMA (buffer_load_dwordx4 ... lds), no staging registers and no ds_write ----
+  // A tile image is 512 16-byte chunks per operand; wave-instruction i of wave w fills linear chunks
+  // [i*256 + w*64, +64).  The LDS destination of an LDS-DMA is lane-linear, so the swizzles of tile_off() /
+  // v_off() are applied by choosing which (row, chunk) each lane FETCHES.
+  int voff_k0, voff_k1, voff_v0, voff_v1;
+  {
+    int r, cc;
+    tile_pos(tid, r, cc);
+    voff_k0 = (r * ld + dmodel + hd * 64 + cc * 8) * 2;
+    tile_pos(256 + tid, r, cc);
+    voff_k1 = (r * ld + dmodel + hd * 64 + cc * 8) * 2;
+    // inverse of v_off: chunk position q = 64 (key>>3) + 32 (ch>>2) + 4 (key&7) + ((ch&3) ^ ((key>>2)&3))
+    auto v_src = [&](int q) {
+      const int kg = q >> 6, half = (q >> 5) & 1, k7 = (q >> 2) & 7, x = q & 3;
+      const int key = 8 * kg + k7;
+      const int ch = 4 * half + (x ^ ((key >> 2) & 3));
+      return (key * ld + 2 * dmodel + hd * 64 + ch * 8) * 2;
+    };
+    voff_v0 = v_src(tid);
+    voff_v1 = v_src(256 + tid);
+  }
+  const int tile_stride = KT * ld * 2;
+  char* const dma_dst = smem + ((tid & ~63) << 4);   // wave-uniform; the hardware adds lane * 16
+#define ATTN_STAGE_TILE(t, BUFI)                                                                              \
+  {                                                                                                           \
+    const int so_ = (t) * tile_stride;                                                                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dma_dst + (BUFI) * BUF_BYTES), 16, voff_k0, so_, 0, 0);        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dma_dst + (BUFI) * BUF_BYTES + 4096), 16, voff_k1, so_, 0, 0); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES), 16, voff_v0, so_, 0, 0);        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES + 4096), 16, voff_v1, so_, 0, 0); \
+  }
 
-  f32x16_t o[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-
-  // transposed-read lane constants
+  // ---- per-lane LDS read bases (see tile_off / v_off: the kt, s2, dvt, jj and buffer terms are immediates) ----
+  const int p_l = l31 >> 1;
+  const int bslot = (((l31 & 1) << 3) | h) ^ (p_l & 15);
+  const char* const ka0 = smem + (p_l << 8) + ((bslot ^ 0) << 4);
+  const char* const ka1 = smem + (p_l << 8) + ((bslot ^ 2) << 4);
+  const char* const ka2 = smem + (p_l << 8) + ((bslot ^ 4) << 4);
+  const char* const ka3 = smem + (p_l << 8) + ((bslot ^ 6) << 4);
   const int g16 = lane >> 4;                 // 16-lane group 0..3
   const int tr_q = (lane & 15) >> 2;         // row inside the 4-row block
   const int tr_p = lane & 3;
   const int tr_ch = 2 * (g16 & 1) + (tr_p >> 1);
-  const int tr_b8 = 8 * (tr_p & 1);
+  const int vl0 = 64 * (4 * h + tr_q) + 16 * (tr_ch ^ h) + 8 * (tr_p & 1);
+  const char* const va0 = smem + vl0;          // jj = 0
+  const char* const va1 = smem + (vl0 ^ 32);   // jj = 1: (key >> 2) & 3 gains 2 -> chunk index ^ 2
+
+  f32x16_t o0, o1, lacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; lacc[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
 
   const int nt = (tokens + KT - 1) / KT;
-  load_tile(0);
-  write_tile(0);
+  ATTN_STAGE_TILE(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // Retire the Q loads here: otherwise hipcc's waitcnt pass re-waits for the Q registers inside the loop.
+  asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
 
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nt) load_tile(t + 1);
-    const char* k_t = smem[buf][0];
-    const char* v_t = smem[buf][1];
-
-    // ---- S^T = K Q^T : two 32-key subtiles ----
-    f32x16_t sacc[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const s16x8_t kf = *reinterpret_cast<const s16x8_t*>(k_t + tile_off(32 * kt + l31, 2 * s + h));
-        sacc[kt] = mfma32<DT>(kf, qf[s], sacc[kt]);
-      }
+  int t = 0;
+  for (; t + 1 < nt; ++t) {      // every tile but the last: the DMA of tile t + 1 flies under the MFMAs of t
+    if (t & 1) {
+      ATTN_STAGE_TILE(t + 1, 0)
+      attn_tile<DT, 1, false, VAR>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, lacc, m_run, l_run, t, tokens, h, c);
+    } else {
+      ATTN_STAGE_TILE(t + 1, 1)
+      attn_tile<DT, 0, false, VAR>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, lacc, m_run, l_run, t, tokens, h, c);
     }
-    if (t == nt - 1) {  // ragged last tile: keys >= tokens contribute nothing
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KT + 32 * kt + acc_row(r, h);
-          if (key >= tokens) sacc[kt][r] = -INFINITY;
-        }
-    }
-
-    // ---- online softmax (lane = one query column; 32 of the tile's 64 keys are in this lane) ----
-    float tmax = sacc[0][0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[0][r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[1][r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    float psum = 0.f;
-    s16x8_t pf[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      float p[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], c, -mc));
-        psum += p[r];
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        union { s16x8_t v; unsigned u[4]; } cv;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cv.u[j] = pack2_h16<DT>(p[8 * s2 + 2 * j], p[8 * s2 + 2 * j + 1]);
-        pf[kt][s2] = cv.v;
-      }
-    }
-    l_run = l_run * alpha + psum;
-    if (!__all(m_new == m_run)) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    }
-    m_run = m_new;
-
-    // ---- O^T += V^T P^T ----
-#pragma unroll
-    for (int dvt = 0; dvt < 2; ++dvt) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int key0 = 32 * kt + 16 * s2 + 4 * h + tr_q;
-          union { s16x8_t v; s16x4_t hlf[2]; } vf;
-          vf.hlf[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t*)(v_t + v_off(key0, 4 * dvt + tr_ch) + tr_b8));
-          vf.hlf[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t*)(v_t + v_off(key0 + 8, 4 * dvt + tr_ch) + tr_b8));
-          o[dvt] = mfma32<DT>(vf.v, pf[kt][s2], o[dvt]);
-        }
-      }
-    }
-
-    if (t + 1 < nt) write_tile(buf ^ 1);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed ...
+    __syncthreads();                                    // ... and everybody's have, and everybody is done reading
   }
+  if (t & 1) attn_tile<DT, 1, true, VAR>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, lacc, m_run, l_run, t, tokens, h, c);
+  else       attn_tile<DT, 0, true, VAR>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, lacc, m_run, l_run, t, tokens, h, c);
 
   // ---- normalise and store: lane owns query row `qrow`, columns 32 dvt + 8 g + 4 h + {0..3} ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  float l_tot;
+  {
+    const unsigned lb = __float_as_uint(l_run);
+    const auto sw = __builtin_amdgcn_permlane32_swap(lb, lb, false, false);
+    l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    if constexpr (VAR & 2) l_tot = lacc[0];
+  }
   const float inv = 1.0f / l_tot;
   if (qrow < tokens) {
-    unsigned short* orow = out + ((int64_t)b * tokens + qrow) * dmodel + hd * 64;
+    unsigned short* orow = out + ((int64_t)b * tokens + qrow) * dmodel + hd * 64 + 4 * h;
 #pragma unroll
-    for (int dvt = 0; dvt < 2; ++dvt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 pk;
-        pk.x = pack2_h16<DT>(o[dvt][4 * g + 0] * inv, o[dvt][4 * g + 1] * inv);
-        pk.y = pack2_h16<DT>(o[dvt][4 * g + 2] * inv, o[dvt][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(orow + 32 * dvt + 8 * g + 4 * h) = pk;
-      }
+    for (int g = 0; g < 4; ++g) {
+      uint2 pk;
+      pk.x = pack2_h16<DT>(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv);
+      pk.y = pack2_h16<DT>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+      *reinterpret_cast<uint2*>(orow + 8 * g) = pk;
+      pk.x = pack2_h16<DT>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv);
+      pk.y = pack2_h16<DT>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+      *reinterpret_cast<uint2*>(orow + 32 + 8 * g) = pk;
+    }
   }
+#undef ATTN_STAGE_TILE
 }
 
 }  // namespace
@@ -207,20 +277,27 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const unsigned short* __re
 extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads,
                                int32_t dtype, void* stream) {
   if (!qkv || !out || batch <= 0 || tokens <= 0 || heads <= 0) return VITTF_ERR_INVALID_ARG;
+  // 32-bit byte offsets inside one slice's qkv rows (buffer addressing)
+  if ((int64_t)(tokens + KT) * heads * 64 * 3 * 2 > 0x7fffffffLL) return VITTF_ERR_INVALID_ARG;
   const int q_tiles = (tokens + QT - 1) / QT;
   const int64_t total64 = (int64_t)batch * heads * q_tiles;
   if (total64 > (1 << 30)) return VITTF_ERR_INVALID_ARG;
   const int total = (int)total64;
   const float c = 0.125f * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)stream;
+  static const int variant = [] { const char* e = getenv("VITTF_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
+#define VITTF_ATTN_LAUNCH(DTV, VARV)                                                                         \
+  hipLaunchKernelGGL((attn_kernel<DTV, VARV>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,   \
+                     (unsigned short*)out, tokens, heads, q_tiles, total, c)
   if (dtype == VITTF_BF16) {
-    hipLaunchKernelGGL((attn_kernel<VITTF_BF16>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,
-                       (unsigned short*)out, tokens, heads, q_tiles, total, c);
+    if (variant == 1) VITTF_ATTN_LAUNCH(VITTF_BF16, 1); else if (variant == 2) VITTF_ATTN_LAUNCH(VITTF_BF16, 2);
+    else if (variant == 6) VITTF_ATTN_LAUNCH(VITTF_BF16, 6); else VITTF_ATTN_LAUNCH(VITTF_BF16, 0);
   } else if (dtype == VITTF_FP16) {
-    hipLaunchKernelGGL((attn_kernel<VITTF_FP16>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,
-                       (unsigned short*)out, tokens, heads, q_tiles, total, c);
+    if (variant == 1) VITTF_ATTN_LAUNCH(VITTF_FP16, 1); else if (variant == 2) VITTF_ATTN_LAUNCH(VITTF_FP16, 2);
+    else if (variant == 6) VITTF_ATTN_LAUNCH(VITTF_FP16, 6); else VITTF_ATTN_LAUNCH(VITTF_FP16, 0);
   } else {
     return VITTF_ERR_INVALID_ARG;
   }
+#undef VITTF_ATTN_LAUNCH
   return vittf_check_launch();
 }

@@ -35,8 +35,14 @@ template <int DT> __device__ __forceinline__ float h16_to_f32(unsigned short u) 
 __device__ __forceinline__ unsigned short f32_to_f16bits(float x) { return f32_to_h16<VITTF_FP16>(x); }
 __device__ __forceinline__ float f16bits_to_f32(unsigned short u) { return h16_to_f32<VITTF_FP16>(u); }
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// two fp32 -> one dword of two 16-bit values, ONE v_cvt_pk_{bf16,f16}_f32 (round to nearest even)
 template <int DT> __device__ __forceinline__ unsigned pack2_h16(float lo, float hi) {
-  return (unsigned)f32_to_h16<DT>(lo) | ((unsigned)f32_to_h16<DT>(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  if constexpr (DT == VITTF_BF16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
 }
 
 // ---- MFMA 32x32x16, fp32 accumulate.  Lane l: A[row l&31][k 8(l>>5)+j], B[k 8(l>>5)+j][col l&31];

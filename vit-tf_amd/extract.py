@@ -148,9 +148,28 @@ def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=DEFAULT_ENGIN
         ops.pool(model, kbuf, s0, n_slices, n_out, win0, nwin, f0, f1, d, slab, strides)
         del kbuf
     if world > 1:
-        # one exchange step per axis: RCCL all-gather of the pooled slab (in place into `gathered`)
-        torch.distributed.all_gather_into_tensor(gathered.view(-1), slab.reshape(-1).clone(), group=group)
+        _all_gather_slabs(gathered, slab, group)      # the one exchange step per axis
     return gathered, chunk
+
+
+def _all_gather_slabs(gathered, slab, group):
+    """All-gather the ranks' pooled slabs into `gathered` ([world, ...], this rank's slab already in place).
+    RCCL (backend 'nccl') takes the single-tensor form; gloo (CPU tests, or a 2-ranks-on-1-GPU rehearsal) gets
+    the list form, staged through the host when the backend cannot take device tensors."""
+    world = gathered.shape[0]
+    flat = gathered.view(world, -1)
+    mine = slab.reshape(-1).clone()
+    backend = torch.distributed.get_backend(group)
+    if backend == 'nccl':
+        torch.distributed.all_gather_into_tensor(flat.view(-1), mine, group=group)
+        return
+    if flat.is_cuda:
+        host = [torch.empty(flat.shape[1], dtype=flat.dtype) for _ in range(world)]
+        torch.distributed.all_gather(host, mine.cpu(), group=group)
+        for r in range(world):
+            flat[r].copy_(host[r])
+    else:
+        torch.distributed.all_gather(list(flat.unbind(0)), mine, group=group)
 
 
 def _dist_on(group):
