@@ -8,12 +8,15 @@
 //   * 128 x 128 output tile per 256-thread workgroup, 4 waves as 2 (m) x 2 (n), each wave 64 x 64
 //   * K step 64; A and W tiles are [128][64 x 16 bit] images (16 KB each) filled by global_load_lds_dwordx4
 //     (no VGPR staging); the XOR swizzle of tile_off() is applied on the per-lane SOURCE address because the
-//     LDS destination of an LDS-DMA is lane-linear; two buffers, the load of step t+1 overlaps the MFMAs of t
+//     LDS destination of an LDS-DMA is lane-linear; one stage + 4 workgroups per CU (the K = 384 shapes have
+//     only six K steps, so latency is hidden across workgroups, not inside one)
 //   * v_mfma_f32_32x32x16 with W as the A operand and the activations as the B operand, i.e. the wave
 //     computes C^T: a lane then owns ONE activation row and 4 consecutive output columns per register quad,
 //     so bias loads are float4 and stores are 8 B (16-bit out) or 16 B (fp32 residual) per lane
 //   * workgroups are remapped so that consecutive tiles (which share the A panel) run on one XCD's L2
 #include "vittf_common.h"
+
+#include <stdlib.h>
 
 namespace {
 
@@ -52,8 +55,8 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ src, int64_t ld
   }
 }
 
-template <int DT, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const unsigned short* __restrict__ A,
+template <int DT, int EPI, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_kernel(const unsigned short* __restrict__ A,
                                                       const unsigned short* __restrict__ W,
                                                       const float* __restrict__ bias, void* __restrict__ out,
                                                       int64_t rows, int n, int k, int tokens, int n_tiles,
@@ -78,20 +81,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const unsigned short* __re
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = k / BK;
-  stage_tile(A, k, m0, rows - 1, 0, smem, tid);
-  stage_tile(W, k, n0, n - 1, 0, smem + TILE_BYTES, tid);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int t = 0; t < nk; ++t) {
-    char* cur = smem + (t & 1) * 2 * TILE_BYTES;
-    if (t + 1 < nk) {
-      char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-      stage_tile(A, k, m0, rows - 1, (t + 1) * BK, nxt, tid);
-      stage_tile(W, k, n0, n - 1, (t + 1) * BK, nxt + TILE_BYTES, tid);
-    }
-    const char* a_t = cur;
-    const char* w_t = cur + TILE_BYTES;
+  auto compute_tile = [&](const char* a_t, const char* w_t) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int c = 2 * s + h;
@@ -106,38 +96,77 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const unsigned short* __re
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = mfma32<DT>(wf[ni], af[mi], acc[ni][mi]);
     }
+  };
+  if constexpr (NSTAGE == 1) {
+    // one 32 KB stage, four workgroups per CU: the other workgroups' MFMAs cover this one's load latency
+    for (int t = 0; t < nk; ++t) {
+      stage_tile(A, k, m0, rows - 1, t * BK, smem, tid);
+      stage_tile(W, k, n0, n - 1, t * BK, smem + TILE_BYTES, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute_tile(smem, smem + TILE_BYTES);
+      __syncthreads();
+    }
+  } else {
+    stage_tile(A, k, m0, rows - 1, 0, smem, tid);
+    stage_tile(W, k, n0, n - 1, 0, smem + TILE_BYTES, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      char* cur = smem + (t & 1) * 2 * TILE_BYTES;
+      if (t + 1 < nk) {
+        char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+        stage_tile(A, k, m0, rows - 1, (t + 1) * BK, nxt, tid);
+        stage_tile(W, k, n0, n - 1, (t + 1) * BK, nxt + TILE_BYTES, tid);
+      }
+      compute_tile(cur, cur + TILE_BYTES);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
-  // ---- epilogue: lane owns activation row m (per mi) and columns nb + 8g + 4h + {0..3} ----
+  // ---- epilogue ----
+  // The accumulators hold C^T: a lane owns activation row m (per mi) and columns nb + 8g + 4h + {0..3}.
+  if constexpr (EPI == VITTF_EPI_BIAS_RESIDUAL) {
+    // fp32 read-modify-write of the residual stream straight from the registers: 16 B per lane, lanes l / l+32
+    // adjacent (HBM-bound: the stream is read and written once, 8 B per output element)
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int64_t m = m0 + wm * 64 + mi * 32 + l31;
-    if (m >= rows) continue;
-    int64_t orow = m;
-    if constexpr (EPI == VITTF_EPI_KFEAT) {
-      const int64_t b = m / tokens;
-      const int tok = (int)(m - b * tokens);
-      if (tok == 0) continue;  // CLS row dropped (infer.py:202 k[:, 1:])
-      orow = b * (tokens - 1) + tok - 1;
-    }
+    for (int mi = 0; mi < 2; ++mi) {
+      const int64_t m = m0 + wm * 64 + mi * 32 + l31;
+      if (m >= rows) continue;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+      for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = n0 + wn * 64 + ni * 32 + 8 * g + 4 * h;
-        const float4 bv = *reinterpret_cast<const float4*>(bias + col);
-        float v0 = acc[ni][mi][4 * g + 0] + bv.x;
-        float v1 = acc[ni][mi][4 * g + 1] + bv.y;
-        float v2 = acc[ni][mi][4 * g + 2] + bv.z;
-        float v3 = acc[ni][mi][4 * g + 3] + bv.w;
-        if constexpr (EPI == VITTF_EPI_BIAS_RESIDUAL) {
-          float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + orow * n + col);
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + wn * 64 + ni * 32 + 8 * g + 4 * h;
+          const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+          float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + m * n + col);
           float4 x = *p;
-          x.x += v0; x.y += v1; x.z += v2; x.w += v3;
+          x.x += acc[ni][mi][4 * g + 0] + bv.x; x.y += acc[ni][mi][4 * g + 1] + bv.y;
+          x.z += acc[ni][mi][4 * g + 2] + bv.z; x.w += acc[ni][mi][4 * g + 3] + bv.w;
           *p = x;
-        } else {
+        }
+      }
+    }
+  } else {
+    // 16-bit outputs go through LDS so that global stores are whole 256-byte rows (16 lanes x 16 B): storing the
+    // register fragments directly puts 16-byte pieces on 32 different rows per instruction and halves the GEMM's
+    // speed (measured: 0.23 -> 0.12 ms for the qkv shape with the stores removed).
+    // The K loop ended on a barrier, so the operand tiles are dead; C tile rows are padded to 272 B.
+    constexpr int CS = BN * 2 + 16;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int ml = wm * 64 + mi * 32 + l31;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wn * 64 + ni * 32 + 8 * g + 4 * h;
+          const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + nl);
+          float v0 = acc[ni][mi][4 * g + 0] + bv.x;
+          float v1 = acc[ni][mi][4 * g + 1] + bv.y;
+          float v2 = acc[ni][mi][4 * g + 2] + bv.z;
+          float v3 = acc[ni][mi][4 * g + 3] + bv.w;
           if constexpr (EPI == VITTF_EPI_BIAS_GELU) {
             v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
           }
@@ -149,9 +178,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const unsigned short* __re
             pk.x = pack2_h16<DT>(v0, v1);
             pk.y = pack2_h16<DT>(v2, v3);
           }
-          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + orow * n + col) = pk;
+          *reinterpret_cast<uint2*>(smem + ml * CS + nl * 2) = pk;
         }
       }
+    }
+    __syncthreads();
+    unsigned short* o16 = reinterpret_cast<unsigned short*>(out);
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int rl = pass * 16 + (tid >> 4);
+      const int64_t m = m0 + rl;
+      if (m >= rows) continue;
+      int64_t orow = m;
+      if constexpr (EPI == VITTF_EPI_KFEAT) {
+        const int64_t b = m / tokens;
+        const int tok = (int)(m - b * tokens);
+        if (tok == 0) continue;  // CLS row dropped (infer.py:202 k[:, 1:])
+        orow = b * (tokens - 1) + tok - 1;
+      }
+      const uint4 v = *reinterpret_cast<const uint4*>(smem + rl * CS + (tid & 15) * 16);
+      *reinterpret_cast<uint4*>(o16 + orow * n + n0 + (tid & 15) * 8) = v;
     }
   }
 }
@@ -161,19 +207,26 @@ int launch_gemm(const void* a, const void* w, const float* bias, void* out, int6
                 int tokens, hipStream_t st) {
   const int m_tiles = (int)((rows + BM - 1) / BM), n_tiles = n / BN;
   const int total = m_tiles * n_tiles;
-  const size_t lds = 4 * TILE_BYTES;
+  // 1 = one 32 KB operand stage and four workgroups per CU (default: +16 % on the K = 384 shapes, whose six
+  // K steps are too short for a two-stage pipeline to cover the load latency); 2 = double buffer, two per CU
+  static const int nstage = [] { const char* e = getenv("VITTF_GEMM_STAGES"); return e ? atoi(e) : 1; }();
+  const size_t lds = nstage == 1 ? (size_t)BM * (BN * 2 + 16) : (size_t)4 * TILE_BYTES;   // stage(s) / padded C tile
   const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Wp = (const unsigned short*)w;
 #define VITTF_GEMM_CASE(E)                                                                                   \
   case E: {                                                                                                  \
     static bool attr_set = false;                                                                            \
     if (!attr_set) {                                                                                         \
-      (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                   \
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)(4 * TILE_BYTES));                                                      \
       attr_set = true;                                                                                       \
     }                                                                                                        \
-    hipLaunchKernelGGL((gemm_kernel<DT, E>), dim3(total), dim3(256), lds, st, A, Wp, bias, out, rows, n, k,  \
-                       tokens, n_tiles, total);                                                              \
+    if (nstage == 1)                                                                                         \
+      hipLaunchKernelGGL((gemm_kernel<DT, E, 1>), dim3(total), dim3(256), lds, st, A, Wp, bias, out, rows, n, k, \
+                         tokens, n_tiles, total);                                                            \
+    else                                                                                                     \
+      hipLaunchKernelGGL((gemm_kernel<DT, E, 2>), dim3(total), dim3(256), lds, st, A, Wp, bias, out, rows, n, k, \
+                         tokens, n_tiles, total);                                                            \
     break;                                                                                                   \
   }
   switch (epi) {
