@@ -6,7 +6,7 @@
 //
 // The feature volume is F-major fp16: voxel index contiguous, stride Nvox between features.  For the interactive
 // regime (A <= a few dozen) the dot products are HBM-bound: every voxel's 2*F bytes are read ONCE per chunk of 16
-// annotations, coalesced 8 B per lane, and the reference's A*4 B/voxel intermediate never exists.  Query vectors
+// annotations, coalesced 4 B per lane, and the reference's A*4 B/voxel intermediate never exists.  Query vectors
 // are wave-uniform (scalar loads of a transposed [F][16] copy); all arithmetic is fp32 like the reference CPU path.
 #include "vittf_common.h"
 
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const void* __restrict__ fe
 
 // ---------------------------------------------------------------- similarity
 constexpr int ACH = 16;   // annotations per pass over the volume
-constexpr int VPT = 4;    // voxels per thread (8-byte loads)
+constexpr int VPT = 2;    // voxels per thread (4-byte loads): 64^3 voxels -> 2048 waves, 8 per CU (4 per thread left the
+                          // kernel latency-bound at 0.85 TB/s with one wave per SIMD)
 constexpr int MAXC = 8;   // classes handled by one pass (more classes: several launches)
 
 struct SimChunk {
@@ -100,14 +101,14 @@ __global__ __launch_bounds__(256) void sim_accumulate(const unsigned short* __re
     for (int j = 0; j < VPT; ++j) acc[a][j] = 0.f;
   const bool full = v0 + VPT <= nvox;
   if (v0 < nvox) {
-    const bool vec = full && ((nvox & 3) == 0);
+    const bool vec = full && ((nvox & 1) == 0);
+#pragma unroll 8
     for (int ff = 0; ff < f; ++ff) {
       float x[VPT];
       const unsigned short* p = feat + (int64_t)ff * nvox + v0;
       if (vec) {
-        const uint2 raw = *reinterpret_cast<const uint2*>(p);
-        x[0] = f16bits_to_f32((unsigned short)(raw.x & 0xffff)); x[1] = f16bits_to_f32((unsigned short)(raw.x >> 16));
-        x[2] = f16bits_to_f32((unsigned short)(raw.y & 0xffff)); x[3] = f16bits_to_f32((unsigned short)(raw.y >> 16));
+        const unsigned raw = *reinterpret_cast<const unsigned*>(p);
+        x[0] = f16bits_to_f32((unsigned short)(raw & 0xffff)); x[1] = f16bits_to_f32((unsigned short)(raw >> 16));
       } else {
 #pragma unroll
         for (int j = 0; j < VPT; ++j) x[j] = (v0 + j < nvox) ? f16bits_to_f32(p[j]) : 0.f;
@@ -236,7 +237,7 @@ extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int
   if (class_start_host[0] != 0) return VITTF_ERR_INVALID_ARG;
   for (int c = 0; c < classes; ++c)
     if (class_start_host[c + 1] <= class_start_host[c]) return VITTF_ERR_INVALID_ARG;  // empty class: caller drops it
-  if (((uintptr_t)feat & 7) != 0) return VITTF_ERR_INVALID_ARG;
+  if (((uintptr_t)feat & 3) != 0) return VITTF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   char* wsb = (char*)ws;
   unsigned* maxbits = (unsigned*)wsb;
