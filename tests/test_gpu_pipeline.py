@@ -240,3 +240,44 @@ def test_two_ranks_share_one_gpu_rehearsal(gpu, tmp_path):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['value'] > 0 and out['roofline']['achieved'] > 0 and out['cpu_baseline'] is None
+
+
+def test_vitb8_full_size_slice(gpu):
+    """BASELINE configs[3] shape: ViT-B/8 (D = 768, 12 heads), N = 4097; one slice, bf16 and fp16 vs the oracle."""
+    sd = vt.synthetic_state_dict('vitb8', 2)
+    vol, _ = vt.synthetic_volume('sphere_thick', 64, 0.1, 1)
+    vol = vol.float()
+    im_sz, _ = vt.sizing((64, 64, 64), 64, 8)
+    oracle = dino_vit.build_vit('vitb8', sd)
+    imgs = ofv.normalized_slices(vol, 'y')[[31]]
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    with torch.no_grad():
+        ref = ofv.k_tokens(oracle, torch.nn.functional.interpolate(imgs, size=(512, 512), mode='nearest'))[:, 1:]
+    for dt in ('fp16', 'bf16'):
+        model = vt.HipViT(sd, 'vitb8', dt)
+        dvol = vt.DeviceVolume(vol, gpu)
+        got = vt.k_slices(model, dvol, 'y', im_sz, 31, 32).cpu()
+        assert got.shape == (1, 4096, 768)
+        e = rel_fro(got, ref)
+        print(f'vitb8 N=4097 {dt}: rel fro {e:.3e}')
+        assert e <= TOL[dt][0]
+
+
+def test_fos128_long_sequence(gpu):
+    """sub/infer_and_merge.sh preset: feature-output-size 128 -> 1024 x 1024 images, N = 16385 tokens.  A reduced-depth
+    ViT-S keeps the CPU oracle affordable; the attention / GEMM shapes per layer are the real ones."""
+    arch = (384, 2, 6, 8)
+    sd = vt.synthetic_state_dict(arch, 4)
+    vol = torch.rand((16, 16, 2), generator=torch.Generator().manual_seed(6)).half().float()
+    im_sz = (1024, 1024, 16)
+    oracle = dino_vit.build_vit(arch, sd)
+    imgs = ofv.normalized_slices(vol, 'z')[[1]]
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    with torch.no_grad():
+        ref = ofv.k_tokens(oracle, torch.nn.functional.interpolate(imgs, size=(1024, 1024), mode='nearest'))[:, 1:]
+    model = vt.HipViT(sd, arch, 'fp16')
+    got = vt.k_slices(model, vt.DeviceVolume(vol, gpu), 'z', im_sz, 1, 2).cpu()
+    assert got.shape == (1, 128 * 128, 384)
+    e = rel_fro(got, ref)
+    print(f'N=16385 depth-2 fp16: rel fro {e:.3e}')
+    assert e <= TOL['fp16'][0]

@@ -22,9 +22,7 @@
 //   * token count need not be tile aligned (N = f0*f1 + 1): the last key tile is masked to -inf, query rows
 //     past the end are clamped on load and their stores are guarded
 //   * workgroups are remapped so that the q-tiles of one (slice, head) share an XCD's L2 (K/V re-reads)
-#include "vittf_common.h"
-
-#include <stdlib.h>
+#include "attn_common.h"
 
 namespace {
 
@@ -33,26 +31,13 @@ constexpr int KT = 64;    // keys per tile
 constexpr int KV_TILE_BYTES = KT * 64 * 2;  // 8 KB
 constexpr int BUF_BYTES = 2 * KV_TILE_BYTES; // K | V
 
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-
-// V image: [8 key groups][2 column halves] subtiles of 8 keys x 32 columns (512 B), chunk XOR by (key>>2)&3
-__device__ __forceinline__ int v_off(int key, int ch) {
-  return 1024 * (key >> 3) + 512 * (ch >> 2) + 64 * (key & 7) + 16 * ((ch & 3) ^ ((key >> 2) & 3));
-}
-
-__device__ __forceinline__ float max3_f32(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-
 // One 64-key tile for this wave's 32 query rows.  BUF selects the LDS buffer at compile time so that every
 // ds_read offset is an immediate on one of six per-lane base registers.  LAST masks keys >= tokens.
-template <int DT, int BUF, bool LAST, int VAR>
+template <int DT, int BUF, bool LAST>
 __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, const char* ka2, const char* ka3,
                                           const char* va0, const char* va1, const s16x8_t& q0, const s16x8_t& q1,
                                           const s16x8_t& q2, const s16x8_t& q3, f32x16_t& o0, f32x16_t& o1,
-                                          f32x16_t& lacc, float& m_run, float& l_run, int t, int tokens, int h, float c) {
+                                          float& m_run, float& l_run, int t, int tokens, int h, float c) {
   // Two 32-key halves, each carried from S^T to O^T before the next one starts: the score registers (16) and
   // the P fragments (8) of one half are all that is live, which keeps the kernel at 4 waves per SIMD.
 #pragma unroll
@@ -91,10 +76,6 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
       l_run *= alpha;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      if constexpr (VAR & 2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
-      }
       m_run = m_new;
     }
     float psum0 = 0.f, psum1 = 0.f;
@@ -103,9 +84,10 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
     for (int r = 0; r < 16; r += 2) {
       p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -mc));
       p[r + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[r + 1], c, -mc));
-      if constexpr (!(VAR & 2)) { psum0 += p[r]; psum1 += p[r + 1]; }
+      psum0 += p[r];
+      psum1 += p[r + 1];
     }
-    if constexpr (!(VAR & 2)) l_run += psum0 + psum1;
+    l_run += psum0 + psum1;
     s16x8_t pf[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -116,14 +98,6 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
     }
 
     // ---- O^T += V^T P^T for these 32 keys ----
-    if constexpr (VAR & 2) {
-      // row sums on the matrix pipe (which has slack) instead of 16 VALU adds: ones[32][16] . P^T[16][32 q]
-      // puts sum_k P[q][k] -- over the keys of BOTH lane halves -- in every register of lacc
-      constexpr short one = DT == VITTF_BF16 ? (short)0x3F80 : (short)0x3C00;
-      const s16x8_t ones = {one, one, one, one, one, one, one, one};
-      lacc = mfma32<DT>(ones, pf[0], lacc);
-      lacc = mfma32<DT>(ones, pf[1], lacc);
-    }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
@@ -139,12 +113,12 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
         else          o1 = mfma32<DT>(vf, pf[s2], o1);
       }
     }
-    if constexpr (!(VAR & 4)) __builtin_amdgcn_sched_barrier(0);   // keep the halves sequential: interleaving them costs 40 VGPRs and a wave per SIMD
+    __builtin_amdgcn_sched_barrier(0);   // keep the halves sequential: interleaving them costs 40 VGPRs and a wave per SIMD
   }
 }
 
-template <int DT, int VAR>
-__global__ __launch_bounds__(256, (VAR & 2) ? 3 : 4) void attn_kernel(const unsigned short* __restrict__ qkv,
+template <int DT>
+__global__ __launch_bounds__(256, 4) void attn_kernel(const unsigned short* __restrict__ qkv,
                                                       unsigned short* __restrict__ out, int tokens, int heads,
                                                       int q_tiles, int total, float c) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];  // [buffer][K | V]
@@ -220,9 +194,9 @@ __global__ __launch_bounds__(256, (VAR & 2) ? 3 : 4) void attn_kernel(const unsi
   const char* const va0 = smem + vl0;          // jj = 0
   const char* const va1 = smem + (vl0 ^ 32);   // jj = 1: (key >> 2) & 3 gains 2 -> chunk index ^ 2
 
-  f32x16_t o0, o1, lacc;
+  f32x16_t o0, o1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; lacc[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
   const int nt = (tokens + KT - 1) / KT;
@@ -236,16 +210,16 @@ __global__ __launch_bounds__(256, (VAR & 2) ? 3 : 4) void attn_kernel(const unsi
   for (; t + 1 < nt; ++t) {      // every tile but the last: the DMA of tile t + 1 flies under the MFMAs of t
     if (t & 1) {
       ATTN_STAGE_TILE(t + 1, 0)
-      attn_tile<DT, 1, false, VAR>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, lacc, m_run, l_run, t, tokens, h, c);
+      attn_tile<DT, 1, false>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
     } else {
       ATTN_STAGE_TILE(t + 1, 1)
-      attn_tile<DT, 0, false, VAR>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, lacc, m_run, l_run, t, tokens, h, c);
+      attn_tile<DT, 0, false>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed ...
     __syncthreads();                                    // ... and everybody's have, and everybody is done reading
   }
-  if (t & 1) attn_tile<DT, 1, true, VAR>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, lacc, m_run, l_run, t, tokens, h, c);
-  else       attn_tile<DT, 0, true, VAR>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, lacc, m_run, l_run, t, tokens, h, c);
+  if (t & 1) attn_tile<DT, 1, true>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
+  else       attn_tile<DT, 0, true>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
 
   // ---- normalise and store: lane owns query row `qrow`, columns 32 dvt + 8 g + 4 h + {0..3} ----
   float l_tot;
@@ -253,7 +227,6 @@ __global__ __launch_bounds__(256, (VAR & 2) ? 3 : 4) void attn_kernel(const unsi
     const unsigned lb = __float_as_uint(l_run);
     const auto sw = __builtin_amdgcn_permlane32_swap(lb, lb, false, false);
     l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    if constexpr (VAR & 2) l_tot = lacc[0];
   }
   const float inv = 1.0f / l_tot;
   if (qrow < tokens) {
@@ -285,19 +258,14 @@ extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_
   const int total = (int)total64;
   const float c = 0.125f * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)stream;
-  static const int variant = [] { const char* e = getenv("VITTF_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-#define VITTF_ATTN_LAUNCH(DTV, VARV)                                                                         \
-  hipLaunchKernelGGL((attn_kernel<DTV, VARV>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,   \
-                     (unsigned short*)out, tokens, heads, q_tiles, total, c)
   if (dtype == VITTF_BF16) {
-    if (variant == 1) VITTF_ATTN_LAUNCH(VITTF_BF16, 1); else if (variant == 2) VITTF_ATTN_LAUNCH(VITTF_BF16, 2);
-    else if (variant == 6) VITTF_ATTN_LAUNCH(VITTF_BF16, 6); else VITTF_ATTN_LAUNCH(VITTF_BF16, 0);
+    hipLaunchKernelGGL((attn_kernel<VITTF_BF16>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,
+                       (unsigned short*)out, tokens, heads, q_tiles, total, c);
   } else if (dtype == VITTF_FP16) {
-    if (variant == 1) VITTF_ATTN_LAUNCH(VITTF_FP16, 1); else if (variant == 2) VITTF_ATTN_LAUNCH(VITTF_FP16, 2);
-    else if (variant == 6) VITTF_ATTN_LAUNCH(VITTF_FP16, 6); else VITTF_ATTN_LAUNCH(VITTF_FP16, 0);
+    hipLaunchKernelGGL((attn_kernel<VITTF_FP16>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,
+                       (unsigned short*)out, tokens, heads, q_tiles, total, c);
   } else {
     return VITTF_ERR_INVALID_ARG;
   }
-#undef VITTF_ATTN_LAUNCH
   return vittf_check_launch();
 }
