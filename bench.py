@@ -36,11 +36,12 @@ FOS = 64
 
 
 def vit_flops(n_tokens, dim, depth, patch):
-    """Algorithmic FLOPs per slice: (attention, linear layers, patch embed)."""
+    """Algorithmic FLOPs per slice: (attention, qkv/proj/K linears, MLP, patch embed)."""
     attn = (depth - 1) * 4 * n_tokens * n_tokens * dim
-    lin = (depth - 1) * 24 * n_tokens * dim * dim + 2 * n_tokens * dim * dim
+    lin = (depth - 1) * 8 * n_tokens * dim * dim + 2 * n_tokens * dim * dim
+    mlp = (depth - 1) * 16 * n_tokens * dim * dim
     pe = 2 * (n_tokens - 1) * 3 * patch * patch * dim
-    return attn, lin, pe
+    return attn, lin, mlp, pe
 
 
 def make_workload(name):
@@ -192,21 +193,24 @@ def main():
     sim_ms = (time.perf_counter() - ts) / n_rep * 1e3
     nvox = feat_out[0] * feat_out[1] * feat_out[2]
 
-    attn_f, lin_f, pe_f = vit_flops(n_tokens, 384, 12, 8)
+    attn_f, lin_f, mlp_f, pe_f = vit_flops(n_tokens, 384, 12, 8)
     slices_done = my_slices * args.steps
-    flops = {'attention': attn_f * slices_done, 'gemm': lin_f * slices_done}
-    dom = max(('attention', 'gemm'), key=lambda k: prof[k][0])
+    if prof['mlp'][1] == 0:          # unfused MLP: its two GEMMs are counted in the gemm class
+        lin_f, mlp_f = lin_f + mlp_f, 0
+    flops = {'attention': attn_f * slices_done, 'gemm': lin_f * slices_done, 'mlp': mlp_f * slices_done}
+    dom = max(('attention', 'gemm', 'mlp'), key=lambda k: prof[k][0])
     dom_ms, dom_launches = prof[dom]
     achieved = flops[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.dtype]
     roofline = {
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
         'traffic': pmc_traffic(dom, args.engine_batch if my_slices >= args.engine_batch else my_slices),
-        'kernel': {'attention': f'attn_kernel<{args.dtype}>', 'gemm': f'gemm_kernel<{args.dtype}, *>'}[dom],
+        'kernel': {'attention': f'attn_kernel<{args.dtype}>', 'gemm': f'gemm_kernel<{args.dtype}, *>',
+                   'mlp': f'mlp_kernel<{args.dtype}>'}[dom],
         'launches': int(dom_launches), 'avg_launch_ms': round(dom_ms / max(1, dom_launches), 4),
         'flop_per_launch': flops[dom] / max(1, dom_launches),
         'kernel_ms_rank0': {k: round(v[0], 2) for k, v in prof.items()},
-        'whole_vit_tflops': round((attn_f + lin_f + pe_f) * slices_done / (sum(v[0] for v in prof.values()) * 1e-3) / 1e12, 2)
+        'whole_vit_tflops': round((attn_f + lin_f + mlp_f + pe_f) * slices_done / (sum(v[0] for v in prof.values()) * 1e-3) / 1e12, 2)
         if sum(v[0] for v in prof.values()) > 0 else 0.0,
     }
 

@@ -75,6 +75,9 @@ typedef struct vittf_vit_weights {
   const float* fc1_b;    /* [L][4D] */
   const void*  fc2_w;    /* h16 [L][D][4D]   blocks.i.mlp.fc2.weight */
   const float* fc2_b;    /* [L][D] */
+  const void*  fc2_w_perm; /* h16 [L][D][4D] or NULL: fc2_w with the hidden (input) dim re-ordered inside every block of
+                            16 as [0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15] -- the operand order of vittf_mlp_fused;
+                            when non-NULL and D == 384 the engine runs the fused MLP kernel */
   const float* ln1_g;    /* [L][D] */
   const float* ln1_b;    /* [L][D] */
   const float* ln2_g;    /* [L][D] */
@@ -129,7 +132,7 @@ int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit_weights* w
  * durations in ms and the launch counts (arrays of VITTF_KERNEL_CLASSES entries, [host]). */
 typedef enum vittf_kernel_class {
   VITTF_KERNEL_PATCH_EMBED = 0, VITTF_KERNEL_LAYERNORM = 1, VITTF_KERNEL_GEMM = 2, VITTF_KERNEL_ATTENTION = 3,
-  VITTF_KERNEL_CLASSES = 4
+  VITTF_KERNEL_MLP = 4, VITTF_KERNEL_CLASSES = 5
 } vittf_kernel_class;
 int vittf_profiler_enable(int32_t on);
 int vittf_profiler_collect(double* ms_per_class, int64_t* launches_per_class);
@@ -159,6 +162,13 @@ typedef enum vittf_epilogue {
  * `tokens` is only used by VITTF_EPI_KFEAT. */
 int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
                int32_t epilogue, int32_t tokens, int32_t dtype, void* stream);
+
+/* Fused MLP of one block for D == 384:  x[rows][D] (fp32) += fc2(gelu_erf(fc1(h) + b1)) + b2 without ever writing the
+ * [rows][4D] hidden activation.  h: h16 [rows][D] (LayerNorm2 output); w1: h16 [4D][D]; w2_perm: h16 [D][4D] in the
+ * vittf_vit_weights.fc2_w_perm order.  Same result as vittf_gemm(BIAS_GELU) + vittf_gemm(BIAS_RESIDUAL) up to the
+ * rounding of the hidden activation (identical: both round it once to h16). */
+int vittf_mlp_fused(const void* h, const void* w1, const float* b1, const void* w2_perm, const float* b2, float* x,
+                    int64_t rows, int32_t d, int32_t dtype, void* stream);
 
 /* Multi-head self-attention over `batch` independent sequences of `tokens` rows.
  * qkv h16 [batch*tokens][3D] with columns [q | k | v], heads of 64 concatenated inside each third

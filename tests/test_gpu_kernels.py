@@ -107,6 +107,44 @@ def test_gemm_rejects_bad_shapes(gpu):
     assert lib.vittf_gemm(None, _lib.ptr(t), _lib.ptr(f), _lib.ptr(t), 4, 128, 64, 0, 0, 1, _lib.stream_ptr()) == -1
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows', [1, 130, 4097])
+def test_mlp_fused(gpu, dt, rows):
+    """x += fc2(gelu(fc1(h))) with the hidden activation kept in registers, against fp64 (hidden rounded once to the
+    16-bit type, as both the fused and the two-GEMM path do) and against the two-GEMM path itself."""
+    lib = _lib.load()
+    d = 384
+    g = gen(rows)
+    h = torch.randn(rows, d, generator=g).to(TDT[dt])
+    w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt])
+    b1 = 0.3 * torch.randn(4 * d, generator=g)
+    w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
+    b2 = 0.3 * torch.randn(d, generator=g)
+    x0 = torch.randn(rows + 2, d, generator=g) * 3
+    hid = F.gelu(h.double() @ w1.double().t() + b1.double()).to(TDT[dt]).double()
+    ref = x0[:rows].double() + hid @ w2.double().t() + b2.double()
+    hd, w1d, b1d, w2d, b2d = h.to(gpu), w1.to(gpu), b1.to(gpu), w2.to(gpu), b2.to(gpu)
+    w2p = vt.weights.permute_fc2_hidden(w2).to(gpu)
+    xd = x0.to(gpu)
+    _lib.check(lib.vittf_mlp_fused(_lib.ptr(hd), _lib.ptr(w1d), _lib.ptr(b1d), _lib.ptr(w2p), _lib.ptr(b2d), _lib.ptr(xd), rows,
+                                   d, _lib.DTYPES[dt], _lib.stream_ptr()))
+    got = xd.cpu().double()
+    assert torch.equal(got[rows:], x0[rows:].double()), 'wrote past the last row'
+    # a hidden unit whose fp32 pre-activation sits on a rounding boundary may round the other way than in fp64
+    assert ((got[:rows] - ref).abs() <= 3 * EPS[dt] + 1e-4).all()
+    assert rel_fro(got[:rows] - x0[:rows].double(), ref - x0[:rows].double()) <= EPS[dt] / 4
+    # the unfused path: fc1 + GELU GEMM, then fc2 + residual GEMM
+    gbuf = torch.zeros(rows, 4 * d, dtype=TDT[dt], device=gpu)
+    x2 = x0.to(gpu)
+    _lib.check(lib.vittf_gemm(_lib.ptr(hd), _lib.ptr(w1d), _lib.ptr(b1d), _lib.ptr(gbuf), rows, 4 * d, d, _lib.EPI_BIAS_GELU, 0,
+                              _lib.DTYPES[dt], _lib.stream_ptr()))
+    _lib.check(lib.vittf_gemm(_lib.ptr(gbuf), _lib.ptr(w2d), _lib.ptr(b2d), _lib.ptr(x2), rows, d, 4 * d,
+                              _lib.EPI_BIAS_RESIDUAL, 0, _lib.DTYPES[dt], _lib.stream_ptr()))
+    assert torch.allclose(xd[:rows], x2[:rows], rtol=0, atol=2e-4 * float(ref.abs().max()))
+    assert lib.vittf_mlp_fused(_lib.ptr(hd), _lib.ptr(w1d), _lib.ptr(b1d), _lib.ptr(w2p), _lib.ptr(b2d), _lib.ptr(xd), rows,
+                               768, _lib.DTYPES[dt], _lib.stream_ptr()) == -1
+
+
 # ------------------------------------------------------------------------------------------ attention
 def _attn_ref(qkv, batch, tokens, heads):
     d = heads * 64

@@ -28,7 +28,7 @@ def timeit(fn, reps=10, warm=3):
 
 
 def main():
-    what = set(sys.argv[1:]) or {'attn', 'gemm', 'ln', 'sim'}
+    what = set(sys.argv[1:]) or {'attn', 'gemm', 'mlp', 'ln', 'sim'}
     lib = _lib.load()
     dev = torch.device('cuda', 0)
     dt = os.environ.get('DT', 'bf16')
@@ -53,6 +53,16 @@ def main():
             fl = 2 * rows * n * k
             byts = rows * k * 2 + n * k * 2 + rows * n * (8 if epi == 2 else 2)
             print(f'gemm {name:9s} [{rows}x{k}]x[{n}x{k}]^T: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s   {byts / ms / 1e6:.0f} GB/s algorithmic')
+    if 'mlp' in what:
+        hh = torch.randn(rows, d, generator=g).to(TDT[dt]).to(dev)
+        w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(dev)
+        w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
+        w2p = vt.weights.permute_fc2_hidden(w2).to(dev)
+        b1 = torch.randn(4 * d, generator=g).to(dev); b2 = torch.randn(d, generator=g).to(dev)
+        xx = torch.zeros(rows, d, device=dev)
+        ms = timeit(lambda: _lib.check(lib.vittf_mlp_fused(_lib.ptr(hh), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2p), _lib.ptr(b2), _lib.ptr(xx), rows, d, _lib.DTYPES[dt], _lib.stream_ptr())))
+        fl = 16 * rows * d * d
+        print(f'mlp fused  [{rows}x{d}] -> {4 * d} -> {d}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s   (two-GEMM path: fc1+gelu + fc2+res above)')
     if 'ln' in what:
         x = torch.randn(rows, d, generator=g).to(dev)
         w = torch.ones(d, device=dev); b = torch.zeros(d, device=dev)

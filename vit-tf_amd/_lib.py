@@ -22,7 +22,7 @@ class VitConfig(C.Structure):
 
 class VitWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        'pe_w_t', 'pe_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b',
+        'pe_w_t', 'pe_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'fc2_w_perm',
         'ln1_g', 'ln1_b', 'ln2_g', 'ln2_b')]
 
 
@@ -58,6 +58,7 @@ SIGNATURES = {
     'vittf_patch_embed': (C.c_int, [_P(VitConfig), _P(VitWeights), _P(PosEmbed), _P(SliceView), _i32, _i32, _vp, _vp]),
     'vittf_layernorm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, C.c_float, _i32, _vp]),
     'vittf_gemm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'vittf_mlp_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'vittf_pool_slices': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64,
                                     _i64, _vp]),
@@ -92,7 +93,7 @@ def load():
     return lib
 
 
-KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention')
+KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention', 'mlp')
 
 
 def profiler_enable(on=True):

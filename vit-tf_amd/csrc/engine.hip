@@ -143,14 +143,22 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
     { ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
       rc = vittf_layernorm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream); }
     if (rc) return rc;
-    { ProfScope ps(VITTF_KERNEL_GEMM, stream);
-      rc = vittf_gemm(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows,
-                      4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream); }
-    if (rc) return rc;
-    { ProfScope ps(VITTF_KERNEL_GEMM, stream);
-      rc = vittf_gemm(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
-                      4 * d, VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
-    if (rc) return rc;
+    if (d == 384 && w->fc2_w_perm) {
+      ProfScope ps(VITTF_KERNEL_MLP, stream);
+      rc = vittf_mlp_fused(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d,
+                           (const char*)w->fc2_w_perm + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
+                           dt, stream);
+      if (rc) return rc;
+    } else {
+      { ProfScope ps(VITTF_KERNEL_GEMM, stream);
+        rc = vittf_gemm(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows,
+                        4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream); }
+      if (rc) return rc;
+      { ProfScope ps(VITTF_KERNEL_GEMM, stream);
+        rc = vittf_gemm(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
+                        4 * d, VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
+      if (rc) return rc;
+    }
   }
   return VITTF_OK;
 }

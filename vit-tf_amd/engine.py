@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .weights import arch_of, fold_patch_embed, interpolate_pos_embed
+from .weights import arch_of, fold_patch_embed, interpolate_pos_embed, permute_fc2_hidden
 
 _TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.FP16: torch.float16}
 
@@ -33,7 +33,7 @@ class HipViT:
     (the reference's own GPU autocast type, infer.py:309) for the MFMA operands.
     """
 
-    def __init__(self, state_dict, arch='vits8', dtype='bf16', device=None):
+    def __init__(self, state_dict, arch='vits8', dtype='bf16', device=None, fused_mlp=None):
         self.lib = _lib.require_device()
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         dim, depth, heads, patch = arch_of(arch)
@@ -62,7 +62,15 @@ class HipViT:
             'ln1_g': stack('blocks.{}.norm1.weight', torch.float32), 'ln1_b': stack('blocks.{}.norm1.bias', torch.float32),
             'ln2_g': stack('blocks.{}.norm2.weight', torch.float32), 'ln2_b': stack('blocks.{}.norm2.bias', torch.float32),
         }
-        self.weights = _lib.VitWeights(**{k: v.data_ptr() for k, v in self._t.items()})
+        ptrs = {k: v.data_ptr() for k, v in self._t.items()}
+        ptrs['fc2_w_perm'] = None
+        if fused_mlp is None:                   # opt-in: parity-green but not yet faster than the two GEMMs (mlp.hip)
+            import os
+            fused_mlp = os.environ.get('VITTF_FUSED_MLP', '0') == '1'
+        if fused_mlp and dim == 384:           # the fused MLP kernel's register budget is sized for ViT-S
+            self._t['fc2_w_perm'] = permute_fc2_hidden(self._t['fc2_w'])
+            ptrs['fc2_w_perm'] = self._t['fc2_w_perm'].data_ptr()
+        self.weights = _lib.VitWeights(**ptrs)
         self._cls = sd['cls_token'].reshape(1, 1, dim)
         self._pos = sd['pos_embed']
         self._pos_cache = {}

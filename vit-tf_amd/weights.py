@@ -151,3 +151,14 @@ def interpolate_pos_embed(pos_embed, rows, cols, patch):
         raise ValueError(f'position-embedding grid {tuple(grid.shape[-2:])} != token grid {(r0, c0)}')
     grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
     return torch.cat((pos_embed[:, :1].float(), grid), dim=1)
+
+
+FC2_PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+
+def permute_fc2_hidden(w2):
+    """fc2 weight [..., D, 4D] with its hidden (input) dim re-ordered inside every block of 16: the k order in which
+    the fused MLP kernel's second MFMA consumes the first one's accumulator registers (include/vittf.h, fc2_w_perm)."""
+    hid = w2.shape[-1]
+    idx = (torch.arange(hid).view(-1, 16)[:, list(FC2_PERM16)]).reshape(-1)
+    return w2[..., idx].contiguous()
