@@ -281,3 +281,24 @@ def test_fos128_long_sequence(gpu):
     e = rel_fro(got, ref)
     print(f'N=16385 depth-2 fp16: rel fro {e:.3e}')
     assert e <= TOL['fp16'][0]
+
+
+def test_optional_paths_agree_with_default(gpu):
+    """Opt-in engine paths (fused MLP kernel, two stream lanes) compute the same feature volume as the default path:
+    stream lanes bit for bit, the fused MLP up to fp32 summation order inside the MLP."""
+    arch = (384, 2, 6, 8)
+    sd = vt.synthetic_state_dict(arch, 9)
+    vol = (torch.rand((16, 24, 40), generator=torch.Generator().manual_seed(4)) * 2 - 1).half().float()
+    base = vt.feature_volume(vol, vt.HipViT(sd, arch, 'bf16'), 2, 'all', engine_batch=4).cpu()
+    old = vt.extract.STREAM_LANES
+    try:
+        vt.extract.STREAM_LANES = 3
+        lanes = vt.feature_volume(vol, vt.HipViT(sd, arch, 'bf16'), 2, 'all', engine_batch=4).cpu()
+    finally:
+        vt.extract.STREAM_LANES = old
+    assert torch.equal(base, lanes)
+    fused = vt.feature_volume(vol, vt.HipViT(sd, arch, 'bf16', fused_mlp=True), 2, 'all', engine_batch=4).cpu()
+    assert rel_fro(fused, base) < 1e-3
+    oracle = dino_vit.build_vit(arch, sd)
+    ref = ofv.feature_volume(vol, oracle, 8, 2, 'all', batch_size=8)
+    assert rel_fro(fused, ref) <= TOL['bf16'][0] and rel_fro(base, ref) <= TOL['bf16'][0]

@@ -94,23 +94,27 @@ class HipViT:
             self._pos_cache[key] = (_lib.PosEmbed(cls0.data_ptr(), patch.data_ptr()), cls0, patch)
         return self._pos_cache[key]
 
-    def workspace(self, batch, tokens):
+    def workspace(self, batch, tokens, lane=0):
+        """Workspace of stream lane `lane` (each concurrently running batch needs its own)."""
         need = self.lib.vittf_vit_workspace_bytes(C.byref(self.cfg), batch, tokens)
         if need == 0:
             raise _lib.VittfError('unsupported ViT configuration for the HIP engine')
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(lane)
+        if ws is None or ws.numel() < need:
+            self._ws[lane] = None
+            ws = self._ws[lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
-    def k_features(self, view, slice0, batch, out, part=1):
+    def k_features(self, view, slice0, batch, out, part=1, lane=0):
         """Run slices [slice0, slice0+batch) of `view` (a _lib.SliceView) through the ViT and write the
         hooked qkv third (`part`: 0 q, 1 k, 2 v) of the patch tokens as fp16 into `out`
         (tensor of >= batch * f0*f1 * D halves)."""
         p = self.patch_size
         tokens = (view.out_rows // p) * (view.out_cols // p) + 1
         pos, _, _ = self.pos_for(view.out_rows, view.out_cols)
-        ws = self.workspace(batch, tokens)
+        ws = self.workspace(batch, tokens, lane)
         assert out.dtype == torch.float16 and out.is_contiguous() and out.numel() >= batch * (tokens - 1) * self.embed_dim
         rc = self.lib.vittf_vit_k_features(C.byref(self.cfg), C.byref(self.weights), C.byref(pos), C.byref(view),
                                            slice0, batch, part, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
