@@ -206,18 +206,22 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const unsigned short* __re
   // Retire the Q loads here: otherwise hipcc's waitcnt pass re-waits for the Q registers inside the loop.
   asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
 
+  // N = f0*f1 + 1 leaves the last q-tile with a single valid row: waves whose 32 rows are all past the end keep
+  // staging and synchronising but skip the arithmetic (3 of 4 waves in 1 of 33 workgroups at N = 4097)
+  const bool active = __builtin_amdgcn_readfirstlane(qt * QT + wave * 32) < tokens;
   int t = 0;
   for (; t + 1 < nt; ++t) {      // every tile but the last: the DMA of tile t + 1 flies under the MFMAs of t
     if (t & 1) {
       ATTN_STAGE_TILE(t + 1, 0)
-      attn_tile<DT, 1, false>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
+      if (active) attn_tile<DT, 1, false>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
     } else {
       ATTN_STAGE_TILE(t + 1, 1)
-      attn_tile<DT, 0, false>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
+      if (active) attn_tile<DT, 0, false>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed ...
     __syncthreads();                                    // ... and everybody's have, and everybody is done reading
   }
+  if (!active) return;          // no barrier after this point
   if (t & 1) attn_tile<DT, 1, true>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
   else       attn_tile<DT, 0, true>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
 
