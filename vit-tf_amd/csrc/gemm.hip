@@ -128,24 +128,42 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_kernel(const un
   // ---- epilogue ----
   // The accumulators hold C^T: a lane owns activation row m (per mi) and columns nb + 8g + 4h + {0..3}.
   if constexpr (EPI == VITTF_EPI_BIAS_RESIDUAL) {
-    // fp32 read-modify-write of the residual stream straight from the registers: 16 B per lane, lanes l / l+32
-    // adjacent (HBM-bound: the stream is read and written once, 8 B per output element)
+    // fp32 read-modify-write of the residual stream, also re-tiled through LDS so that every global access is a
+    // whole 256-byte row segment: two passes of 64 columns (the 128 x 64 fp32 half tile is 32 KB + padding)
+    constexpr int CSF = 64 * 4 + 16;
+    float* xo = reinterpret_cast<float*>(out);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int64_t m = m0 + wm * 64 + mi * 32 + l31;
-      if (m >= rows) continue;
+    for (int half = 0; half < 2; ++half) {
+      if (half) __syncthreads();
+      if (wn == half) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
+        for (int mi = 0; mi < 2; ++mi) {
+          const int ml = wm * 64 + mi * 32 + l31;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = n0 + wn * 64 + ni * 32 + 8 * g + 4 * h;
-          const float4 bv = *reinterpret_cast<const float4*>(bias + col);
-          float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + m * n + col);
-          float4 x = *p;
-          x.x += acc[ni][mi][4 * g + 0] + bv.x; x.y += acc[ni][mi][4 * g + 1] + bv.y;
-          x.z += acc[ni][mi][4 * g + 2] + bv.z; x.w += acc[ni][mi][4 * g + 3] + bv.w;
-          *p = x;
+          for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int nl = ni * 32 + 8 * g + 4 * h;          // column inside this 64-wide half
+              const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + half * 64 + nl);
+              float4 v;
+              v.x = acc[ni][mi][4 * g + 0] + bv.x; v.y = acc[ni][mi][4 * g + 1] + bv.y;
+              v.z = acc[ni][mi][4 * g + 2] + bv.z; v.w = acc[ni][mi][4 * g + 3] + bv.w;
+              *reinterpret_cast<float4*>(smem + ml * CSF + nl * 4) = v;
+            }
+          }
         }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int rl = pass * 16 + (tid >> 4);
+        const int64_t m = m0 + rl;
+        if (m >= rows) continue;
+        const float4 d = *reinterpret_cast<const float4*>(smem + rl * CSF + (tid & 15) * 16);
+        float4* p = reinterpret_cast<float4*>(xo + m * n + n0 + half * 64 + (tid & 15) * 4);
+        float4 x = *p;
+        x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
+        *p = x;
       }
     }
   } else {
@@ -210,7 +228,7 @@ int launch_gemm(const void* a, const void* w, const float* bias, void* out, int6
   // 1 = one 32 KB operand stage and four workgroups per CU (default: +16 % on the K = 384 shapes, whose six
   // K steps are too short for a two-stage pipeline to cover the load latency); 2 = double buffer, two per CU
   static const int nstage = [] { const char* e = getenv("VITTF_GEMM_STAGES"); return e ? atoi(e) : 1; }();
-  const size_t lds = nstage == 1 ? (size_t)BM * (BN * 2 + 16) : (size_t)4 * TILE_BYTES;   // stage(s) / padded C tile
+  const size_t lds = nstage == 1 ? (size_t)BM * (BN * 2 + 16) : (size_t)4 * TILE_BYTES;   // stage(s) / padded C tile (16-bit: 128 x 272 B; fp32 half tile: 128 x 272 B)
   const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Wp = (const unsigned short*)w;
 #define VITTF_GEMM_CASE(E)                                                                                   \

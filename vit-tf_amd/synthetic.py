@@ -42,13 +42,22 @@ def synthetic_volume(name='torus_filled', size=128, noise=0.0, seed=0):
 
 def ct_like_volume(size=512, seed=0):
     """HU-like air / soft tissue / bone-shell volume with Gaussian noise + labels 0..3
-    (SURVEY.md 8d): -1000 + 1400*sphere_filled + 400*torus_filled + 2000*sphere_thick + 30*N(0,1)."""
-    s = shapes(size)
+    (SURVEY.md 8d): -1000 + 1400*sphere_filled + 400*torus_filled + 2000*sphere_thick + 30*N(0,1).
+    Built by broadcasting 1-D coordinate arrays (a 512^3 position grid would cost 1.6 GB per rank)."""
+    ls = torch.linspace(-1, 1, size)
+    # meshgrid(..., indexing='xy') of shapes(): component 0 varies along dim 1, component 1 along dim 0
+    px, py, pz = ls.view(1, size, 1), ls.view(size, 1, 1), ls.view(1, 1, size)
+    rho2 = px * px + py * py                                  # (size, size, 1)
+    sph = torch.sqrt(rho2 + pz * pz) - 0.5
+    q = torch.sqrt(rho2) - 0.5
+    tor = torch.sqrt(q * q + pz * pz) - 0.2
+    sphere_filled, torus_filled, sphere_thick = sph <= 0, tor <= 0, sph.abs() < 0.05
     g = torch.Generator().manual_seed(seed)
-    vol = -1000.0 + 1400.0 * s['sphere_filled'] + 400.0 * s['torus_filled'] + 2000.0 * s['sphere_thick']
-    vol = vol + 30.0 * torch.randn(vol.shape, generator=g)
+    vol = torch.full((size, size, size), -1000.0)
+    vol += 1400.0 * sphere_filled + 400.0 * torus_filled + 2000.0 * sphere_thick
+    vol += 30.0 * torch.randn(vol.shape, generator=g)
     label = torch.zeros(vol.shape, dtype=torch.uint8)
-    label[s['sphere_filled'] > 0.5] = 1
-    label[s['torus_filled'] > 0.5] = 2
-    label[s['sphere_thick'] > 0.5] = 3
+    label[sphere_filled] = 1
+    label[torus_filled] = 2
+    label[sphere_thick] = 3
     return vol.half(), label
