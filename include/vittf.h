@@ -154,8 +154,11 @@ typedef enum vittf_epilogue {
   VITTF_EPI_BIAS = 0,        /* out h16 [rows][n] = a.w^T + bias */
   VITTF_EPI_BIAS_GELU = 1,   /* out h16 [rows][n] = gelu_erf(a.w^T + bias)        (Mlp.fc1 + nn.GELU) */
   VITTF_EPI_BIAS_RESIDUAL = 2,/* out fp32 [rows][n] += a.w^T + bias                (x = x + proj/fc2(...)) */
-  VITTF_EPI_KFEAT = 3        /* out fp16: rows whose (row % tokens) == 0 (CLS) are dropped, the others are
+  VITTF_EPI_KFEAT = 3,       /* out fp16: rows whose (row % tokens) == 0 (CLS) are dropped, the others are
                                 written densely: out[(row/tokens)*(tokens-1) + row%tokens - 1][n] */
+  VITTF_EPI_BIAS_QKV = 4     /* as VITTF_EPI_BIAS, but columns [0, n/3) (the q third of Attention.qkv) are multiplied by
+                                log2(e)/8 before the single rounding to h16: the softmax scale and the exp -> exp2 base
+                                change folded into q, for vittf_attention(..., q_prescaled = 1) */
 } vittf_epilogue;
 
 /* out = epilogue(a[rows][k] . w[n][k]^T + bias[n]);  a, w: h16; k % 64 == 0, n % 128 == 0.
@@ -172,9 +175,11 @@ int vittf_mlp_fused(const void* h, const void* w1, const float* b1, const void* 
 
 /* Multi-head self-attention over `batch` independent sequences of `tokens` rows.
  * qkv h16 [batch*tokens][3D] with columns [q | k | v], heads of 64 concatenated inside each third
- * (layout of Attention.qkv's output); out h16 [batch*tokens][D] = softmax(q k^T / 8) v per head. */
+ * (layout of Attention.qkv's output); out h16 [batch*tokens][D] = softmax(q k^T / 8) v per head.
+ * q_prescaled = 0: q as the model produces it.  q_prescaled = 1: q already multiplied by log2(e)/8
+ * (VITTF_EPI_BIAS_QKV) -- same result, computed by the faster lazy-maximum kernel the engine uses. */
 int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
-                    void* stream);
+                    int32_t q_prescaled, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Feature-volume epilogue (infer.py:201-203 permute_out, :329 AdaptiveAvgPool3d, :330-332 axis sum).

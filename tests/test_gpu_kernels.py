@@ -146,78 +146,94 @@ def test_mlp_fused(gpu, dt, rows):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def _attn_ref(qkv, batch, tokens, heads):
+QSCALE = 0.125 * 1.4426950408889634      # log2(e) / 8, what VITTF_EPI_BIAS_QKV folds into q
+
+
+def _prescale(qkv, heads, dt):
+    """q third multiplied by log2(e)/8 in fp32 and rounded once, as the engine's qkv epilogue does."""
+    out = qkv.float().clone()
+    out[:, :heads * 64] *= QSCALE
+    return out.to(TDT[dt])
+
+
+def _attn_ref(qkv, batch, tokens, heads, pre=0):
     d = heads * 64
     x = qkv.double().view(batch, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4)
     q, k, v = x[0], x[1], x[2]
-    att = (q @ k.transpose(-2, -1)) * 0.125
+    att = (q @ k.transpose(-2, -1)) * (np.log(2.0) if pre else 0.125)       # pre-scaled q: scores are in exp2 units
     return (att.softmax(-1) @ v).transpose(1, 2).reshape(batch * tokens, d)
 
 
-def _run_attn(gpu, qkv, batch, tokens, heads, dt):
+def _run_attn(gpu, qkv, batch, tokens, heads, dt, pre=0):
     lib = _lib.load()
     qd = qkv.to(gpu)
     out = torch.full((batch * tokens + 2, heads * 64), 7.0, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], _lib.stream_ptr()))
+    _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], pre, _lib.stream_ptr()))
     torch.cuda.synchronize()
     got = out.float().cpu().double()
     assert (got[batch * tokens:] == 7.0).all(), 'wrote past the last row'
     return got[:batch * tokens]
 
 
+@pytest.mark.parametrize('pre', [0, 1])
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('batch,tokens,heads', [(1, 1, 2), (2, 17, 2), (1, 64, 2), (3, 65, 2), (1, 128, 6), (2, 129, 2),
                                                 (1, 200, 6), (2, 577, 2), (1, 1025, 2)])
-def test_attention_small(gpu, dt, batch, tokens, heads):
+def test_attention_small(gpu, dt, batch, tokens, heads, pre):
     g = gen(batch * 1000 + tokens)
     qkv = torch.randn(batch * tokens, 3 * heads * 64, generator=g)
     qkv[:, :2 * heads * 64] *= 1.6          # logits with a std of ~2.5: a peaked softmax
-    qkv = qkv.to(TDT[dt])
-    ref = _attn_ref(qkv, batch, tokens, heads)
-    got = _run_attn(gpu, qkv, batch, tokens, heads, dt)
+    qkv = _prescale(qkv, heads, dt) if pre else qkv.to(TDT[dt])
+    ref = _attn_ref(qkv, batch, tokens, heads, pre)
+    got = _run_attn(gpu, qkv, batch, tokens, heads, dt, pre)
     vmax = float(qkv[:, 2 * heads * 64:].float().abs().max())
     # P is rounded to the 16-bit type before the second product, the output once more
     assert rel_fro(got, ref) <= 3 * EPS[dt]
     assert max_abs(got, ref) <= 6 * EPS[dt] * vmax
 
 
+@pytest.mark.parametrize('pre', [0, 1])
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-def test_attention_rescale_branch(gpu, dt):
-    """Force the running maximum to jump in a late key tile (the online-softmax rescale path) and to sit in the
-    ragged last tile; a uniform-random check never exercises that."""
+@pytest.mark.parametrize('gain', [12.0, 60.0])
+def test_attention_rescale_branch(gpu, dt, pre, gain):
+    """Force the maximum to jump in a late key tile and in the ragged last tile: the online-softmax rescale path of
+    the plain kernel and the overflow-triggered slow path of the lazy-maximum kernel (gain 60: scores 2^170 above
+    the first tile's, past fp32's exponent range); a uniform-random check exercises neither."""
     batch, tokens, heads = 1, 333, 2
     g = gen(4)
     qkv = torch.randn(batch * tokens, 3 * heads * 64, generator=g) * 0.5
     q = qkv[:, :128].view(tokens, 2, 64)
     k = qkv[:, 128:256].view(tokens, 2, 64)
     for key_row in (5, 200, 332):                       # first tile, a middle tile, the ragged last tile
-        k[key_row, 0] = q[7 + key_row % 50, 0] * 12.0   # one query row suddenly matches this key strongly
-    qkv = qkv.to(TDT[dt])
-    ref = _attn_ref(qkv, batch, tokens, heads)
-    got = _run_attn(gpu, qkv, batch, tokens, heads, dt)
+        k[key_row, 0] = q[7 + key_row % 50, 0] * gain   # one query row suddenly matches this key strongly
+    k[40, 1] = q[3, 1] * -gain                          # and one strongly negative score
+    qkv = _prescale(qkv, heads, dt) if pre else qkv.to(TDT[dt])
+    ref = _attn_ref(qkv, batch, tokens, heads, pre)
+    got = _run_attn(gpu, qkv, batch, tokens, heads, dt, pre)
     assert torch.isfinite(got).all()
     assert rel_fro(got, ref) <= 3 * EPS[dt]
     assert max_abs(got, ref) <= 6 * EPS[dt] * float(qkv[:, 256:].float().abs().max())
 
 
+@pytest.mark.parametrize('pre', [0, 1])
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-def test_attention_full_size(gpu, dt):
+def test_attention_full_size(gpu, dt, pre):
     """N = 4097 (512^2 image, P = 8), 6 heads: the headline shape; reference in fp64 on the GPU via torch ops."""
     batch, tokens, heads = 2, 4097, 6
     g = gen(77)
     qkv = torch.randn(batch * tokens, 3 * heads * 64, generator=g)
     qkv[:, :2 * heads * 64] *= 1.5
-    qkv = qkv.to(TDT[dt])
+    qkv = _prescale(qkv, heads, dt) if pre else qkv.to(TDT[dt])
     lib = _lib.load()
     qd = qkv.to(gpu)
     out = torch.zeros(batch * tokens, heads * 64, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], _lib.stream_ptr()))
+    _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], pre, _lib.stream_ptr()))
     x = qd.double().view(batch, tokens, 3, heads, 64)
     err2, ref2, mx = 0.0, 0.0, 0.0
     for b in range(batch):
         for h in range(heads):
             q, k, v = x[b, :, 0, h], x[b, :, 1, h], x[b, :, 2, h]
-            r = ((q @ k.t()) * 0.125).softmax(-1) @ v
+            r = ((q @ k.t()) * (np.log(2.0) if pre else 0.125)).softmax(-1) @ v
             d = out[b * tokens:(b + 1) * tokens, h * 64:(h + 1) * 64].double() - r
             err2 += float((d * d).sum()); ref2 += float((r * r).sum()); mx = max(mx, float(d.abs().max()))
     assert (err2 / ref2) ** 0.5 <= 3 * EPS[dt]

@@ -38,11 +38,14 @@ def main():
     if 'attn' in what:
         qkv = torch.randn(rows, 3 * d, generator=g)
         qkv[:, :2 * d] *= 1.5
+        pre = int(os.environ.get('PRE', '1'))
+        if pre:
+            qkv[:, :d] *= 0.125 * 1.4426950408889634
         qkv = qkv.to(TDT[dt]).to(dev)
         out = torch.empty(rows, d, dtype=TDT[dt], device=dev)
-        ms = timeit(lambda: _lib.check(lib.vittf_attention(_lib.ptr(qkv), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], _lib.stream_ptr())))
+        ms = timeit(lambda: _lib.check(lib.vittf_attention(_lib.ptr(qkv), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], pre, _lib.stream_ptr())))
         fl = batch * 4 * tokens * tokens * d
-        print(f'attention  batch {batch} N {tokens}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({fl / ms / 1e9 / 25:.1f} % of 2.5 PF)')
+        print(f'attention  (q_prescaled={pre}) batch {batch} N {tokens}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({fl / ms / 1e9 / 25:.1f} % of 2.5 PF)')
     if 'gemm' in what:
         for name, n, k, epi in (('qkv', 3 * d, d, 0), ('proj+res', d, d, 2), ('fc1+gelu', 4 * d, d, 1), ('fc2+res', d, 4 * d, 2), ('kfeat', d, d, 3)):
             a = torch.randn(rows, k, generator=g).to(TDT[dt]).to(dev)

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libvittf.so')
 BF16, FP16 = 0, 1
 DTYPES = {'bf16': BF16, 'bfloat16': BF16, 'fp16': FP16, 'float16': FP16, 'half': FP16}
 SAMPLE_MODES = {'nearest': 0, 'bilinear': 1, 'trilinear': 1}
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_KFEAT = 0, 1, 2, 3
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_KFEAT, EPI_BIAS_QKV = 0, 1, 2, 3, 4
 
 
 class VitConfig(C.Structure):
@@ -59,7 +59,7 @@ SIGNATURES = {
     'vittf_layernorm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, C.c_float, _i32, _vp]),
     'vittf_gemm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vittf_mlp_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vittf_pool_slices': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64,
                                     _i64, _vp]),
     'vittf_assemble_sum': (C.c_int, [_vp, _vp, _vp, _i32, _P(_i32), _i32, _i32, _i32, _i32, _vp, _vp]),

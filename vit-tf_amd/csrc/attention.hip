@@ -33,19 +33,23 @@ constexpr int BUF_BYTES = 2 * KV_TILE_BYTES; // K | V
 
 // One 64-key tile for this wave's 32 query rows.  BUF selects the LDS buffer at compile time so that every
 // ds_read offset is an immediate on one of six per-lane base registers.  LAST masks keys >= tokens.
-template <int DT, int BUF, bool LAST>
+template <int DT, int BUF, bool LAST, bool PRE>
 __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, const char* ka2, const char* ka3,
                                           const char* va0, const char* va1, const s16x8_t& q0, const s16x8_t& q1,
                                           const s16x8_t& q2, const s16x8_t& q3, f32x16_t& o0, f32x16_t& o1,
-                                          float& m_run, float& l_run, int t, int tokens, int h, float c) {
+                                          f32x16_t& negm, float& m_run, float& l_run, int t, int tokens, int h, float c) {
   // Two 32-key halves, each carried from S^T to O^T before the next one starts: the score registers (16) and
   // the P fragments (8) of one half are all that is live, which keeps the kernel at 4 waves per SIMD.
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
     constexpr int kb = BUF * BUF_BYTES;
     f32x16_t sacc;
+    if constexpr (PRE) {
+      sacc = negm;                       // C input = -M: the MFMA chain returns s' - M, no VALU subtraction
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    }
     sacc = mfma32<DT>(*reinterpret_cast<const s16x8_t*>(ka0 + kb + 4096 * kt), q0, sacc);
     sacc = mfma32<DT>(*reinterpret_cast<const s16x8_t*>(ka1 + kb + 4096 * kt), q1, sacc);
     sacc = mfma32<DT>(*reinterpret_cast<const s16x8_t*>(ka2 + kb + 4096 * kt), q2, sacc);
@@ -58,36 +62,82 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
       }
     }
 
-    // ---- online softmax (lane = one query column; 16 of the half's 32 keys are in this lane) ----
-    // v_max3 through asm: fmaxf() on MFMA outputs makes hipcc insert a canonicalising v_max per operand
-    float tmax = max3_f32(sacc[0], sacc[1], sacc[2]);
-#pragma unroll
-    for (int r = 3; r < 15; r += 2) tmax = max3_f32(tmax, sacc[r], sacc[r + 1]);
-    tmax = max3_f32(tmax, sacc[15], sacc[15]);
-    float m_new;
-    {
-      const unsigned tb = __float_as_uint(tmax);
-      const auto sw = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);   // one of the two holds the other half
-      m_new = max3_f32(m_run, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    const float mc = m_new * c;
-    if (!__all(m_new == m_run)) {   // rare after the first tiles: rescale what was accumulated at the old maximum
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      l_run *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      m_run = m_new;
-    }
-    float psum0 = 0.f, psum1 = 0.f;
     float p[16];
+    if constexpr (PRE) {
+      // ---- lazy-maximum softmax (q arrives pre-scaled by log2(e)/8, so s' is already in exp2 units) ----
+      // M is only a scale: softmax is exact for ANY M as long as nothing overflows, so the common path has no
+      // maximum, no subtraction and no rescale: p = exp2(s' - M) straight from the MFMA result.  M is fixed by
+      // the first 32 keys and raised only when a half's row sum says the values have grown too large for the
+      // 16-bit P (fp16: 2^13; bf16 shares fp32's exponent range: 2^30) -- a rare, wave-uniform slow path.
+      constexpr float THR = DT == VITTF_FP16 ? 8192.f : 1073741824.f;
+      const bool first = (t == 0) && (kt == 0);
+      float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -mc));
-      p[r + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[r + 1], c, -mc));
-      psum0 += p[r];
-      psum1 += p[r + 1];
+      for (int r = 0; r < 16; r += 2) {
+        p[r] = __builtin_amdgcn_exp2f(sacc[r]);
+        p[r + 1] = __builtin_amdgcn_exp2f(sacc[r + 1]);
+        psum0 += p[r];
+        psum1 += p[r + 1];
+      }
+      float ps = psum0 + psum1;
+      if (first || __any(!(ps <= THR))) {
+        float tmax = max3_f32(sacc[0], sacc[1], sacc[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) tmax = max3_f32(tmax, sacc[r], sacc[r + 1]);
+        tmax = max3_f32(tmax, sacc[15], sacc[15]);
+        const unsigned tb = __float_as_uint(tmax);
+        const auto sw = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);
+        tmax = max3_f32(tmax, __uint_as_float(sw[0]), __uint_as_float(sw[1]));      // both lane halves agree
+        const float delta = first ? tmax : max3_f32(tmax, 0.f, 0.f);               // M moves by delta
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run *= alpha;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] -= delta;
+        psum0 = 0.f; psum1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          p[r] = __builtin_amdgcn_exp2f(sacc[r] - delta);
+          p[r + 1] = __builtin_amdgcn_exp2f(sacc[r + 1] - delta);
+          psum0 += p[r];
+          psum1 += p[r + 1];
+        }
+        ps = psum0 + psum1;
+      }
+      l_run += ps;
+    } else {
+      // ---- online softmax (lane = one query column; 16 of the half's 32 keys are in this lane) ----
+      float tmax = max3_f32(sacc[0], sacc[1], sacc[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) tmax = max3_f32(tmax, sacc[r], sacc[r + 1]);
+      tmax = max3_f32(tmax, sacc[15], sacc[15]);
+      float m_new;
+      {
+        const unsigned tb = __float_as_uint(tmax);
+        const auto sw = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);   // one of the two holds the other half
+        m_new = max3_f32(m_run, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      const float mc = m_new * c;
+      if (!__all(m_new == m_run)) {   // rare after the first tiles: rescale what was accumulated at the old maximum
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        l_run *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        m_run = m_new;
+      }
+      float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -mc));
+        p[r + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[r + 1], c, -mc));
+        psum0 += p[r];
+        psum1 += p[r + 1];
+      }
+      l_run += psum0 + psum1;
     }
-    l_run += psum0 + psum1;
     s16x8_t pf[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -117,8 +167,8 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
   }
 }
 
-template <int DT>
-__global__ __launch_bounds__(256, 4) void attn_kernel(const unsigned short* __restrict__ qkv,
+template <int DT, bool PRE>
+__global__ __launch_bounds__(256, PRE ? 2 : 4) void attn_kernel(const unsigned short* __restrict__ qkv,
                                                       unsigned short* __restrict__ out, int tokens, int heads,
                                                       int q_tiles, int total, float c) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];  // [buffer][K | V]
@@ -194,9 +244,9 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const unsigned short* __re
   const char* const va0 = smem + vl0;          // jj = 0
   const char* const va1 = smem + (vl0 ^ 32);   // jj = 1: (key >> 2) & 3 gains 2 -> chunk index ^ 2
 
-  f32x16_t o0, o1;
+  f32x16_t o0, o1, negm;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; negm[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
   const int nt = (tokens + KT - 1) / KT;
@@ -213,17 +263,17 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const unsigned short* __re
   for (; t + 1 < nt; ++t) {      // every tile but the last: the DMA of tile t + 1 flies under the MFMAs of t
     if (t & 1) {
       ATTN_STAGE_TILE(t + 1, 0)
-      if (active) attn_tile<DT, 1, false>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
+      if (active) attn_tile<DT, 1, false, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c);
     } else {
       ATTN_STAGE_TILE(t + 1, 1)
-      if (active) attn_tile<DT, 0, false>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
+      if (active) attn_tile<DT, 0, false, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed ...
     __syncthreads();                                    // ... and everybody's have, and everybody is done reading
   }
   if (!active) return;          // no barrier after this point
-  if (t & 1) attn_tile<DT, 1, true>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
-  else       attn_tile<DT, 0, true>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
+  if (t & 1) attn_tile<DT, 1, true, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c);
+  else       attn_tile<DT, 0, true, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c);
 
   // ---- normalise and store: lane owns query row `qrow`, columns 32 dvt + 8 g + 4 h + {0..3} ----
   float l_tot;
@@ -252,7 +302,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const unsigned short* __re
 }  // namespace
 
 extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads,
-                               int32_t dtype, void* stream) {
+                               int32_t dtype, int32_t q_prescaled, void* stream) {
   if (!qkv || !out || batch <= 0 || tokens <= 0 || heads <= 0) return VITTF_ERR_INVALID_ARG;
   // 32-bit byte offsets inside one slice's qkv rows (buffer addressing)
   if ((int64_t)(tokens + KT) * heads * 64 * 3 * 2 > 0x7fffffffLL) return VITTF_ERR_INVALID_ARG;
@@ -262,14 +312,16 @@ extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_
   const int total = (int)total64;
   const float c = 0.125f * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)stream;
+#define VITTF_ATTN_LAUNCH(DTV, PREV)                                                                        \
+  hipLaunchKernelGGL((attn_kernel<DTV, PREV>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,   \
+                     (unsigned short*)out, tokens, heads, q_tiles, total, c)
   if (dtype == VITTF_BF16) {
-    hipLaunchKernelGGL((attn_kernel<VITTF_BF16>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,
-                       (unsigned short*)out, tokens, heads, q_tiles, total, c);
+    if (q_prescaled) VITTF_ATTN_LAUNCH(VITTF_BF16, true); else VITTF_ATTN_LAUNCH(VITTF_BF16, false);
   } else if (dtype == VITTF_FP16) {
-    hipLaunchKernelGGL((attn_kernel<VITTF_FP16>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,
-                       (unsigned short*)out, tokens, heads, q_tiles, total, c);
+    if (q_prescaled) VITTF_ATTN_LAUNCH(VITTF_FP16, true); else VITTF_ATTN_LAUNCH(VITTF_FP16, false);
   } else {
     return VITTF_ERR_INVALID_ARG;
   }
+#undef VITTF_ATTN_LAUNCH
   return vittf_check_launch();
 }

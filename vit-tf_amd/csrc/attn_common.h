@@ -20,9 +20,8 @@ __device__ __forceinline__ void v_pos(int q, int& key, int& ch) {
   ch = 4 * half + (x ^ ((key >> 2) & 3));
 }
 
-// v_max3 through asm: fmaxf() on MFMA outputs makes hipcc insert a canonicalising v_max per operand
-__device__ __forceinline__ float max3_f32(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// max of three scores.  Plain fmaxf: attention.hip is built with -fno-honor-nans (Makefile), which drops the
+// canonicalising v_max hipcc otherwise inserts per operand and lets it form v_max3_f32 itself.  (An inline-asm
+// v_max3 is NOT an option: asm consumers of an MFMA result get none of the MFMA -> VALU wait states the compiler
+// inserts for its own instructions, and read the accumulator before the matrix pipe has written it.)
+__device__ __forceinline__ float max3_f32(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }

@@ -131,10 +131,10 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
                         VITTF_EPI_KFEAT, tokens, dt, stream);
     }
     { ProfScope ps(VITTF_KERNEL_GEMM, stream);
-      rc = vittf_gemm(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, VITTF_EPI_BIAS, 0, dt, stream); }
+      rc = vittf_gemm(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, VITTF_EPI_BIAS_QKV, 0, dt, stream); }
     if (rc) return rc;
     { ProfScope ps(VITTF_KERNEL_ATTENTION, stream);
-      rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, stream); }
+      rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, /*q_prescaled=*/1, stream); }
     if (rc) return rc;
     { ProfScope ps(VITTF_KERNEL_GEMM, stream);
       rc = vittf_gemm(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d, d,

@@ -188,6 +188,11 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_kernel(const un
           if constexpr (EPI == VITTF_EPI_BIAS_GELU) {
             v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
           }
+          if constexpr (EPI == VITTF_EPI_BIAS_QKV) {
+            // the q third carries the softmax scale and the exp -> exp2 base change: one rounding, like plain q
+            const float sc = (n0 + nl) < n / 3 ? 0.125f * 1.44269504088896340736f : 1.0f;
+            v0 *= sc; v1 *= sc; v2 *= sc; v3 *= sc;
+          }
           uint2 pk;
           if constexpr (EPI == VITTF_EPI_KFEAT) {
             pk.x = pack2_h16<VITTF_FP16>(v0, v1);
@@ -252,6 +257,7 @@ int launch_gemm(const void* a, const void* w, const float* bias, void* out, int6
     VITTF_GEMM_CASE(VITTF_EPI_BIAS_GELU)
     VITTF_GEMM_CASE(VITTF_EPI_BIAS_RESIDUAL)
     VITTF_GEMM_CASE(VITTF_EPI_KFEAT)
+    VITTF_GEMM_CASE(VITTF_EPI_BIAS_QKV)
     default: return VITTF_ERR_INVALID_ARG;
   }
 #undef VITTF_GEMM_CASE
