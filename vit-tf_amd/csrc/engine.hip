@@ -13,6 +13,7 @@
 // Everything is enqueued on the caller's stream; nothing synchronises with the host.
 #include "vittf_common.h"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -130,11 +131,15 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
                         k_out, rows, d, d,
                         VITTF_EPI_KFEAT, tokens, dt, stream);
     }
+    // q pre-scaled + lazy-maximum attention kernel is opt-in: 2 % faster on random data, 7 % slower inside the
+    // pipeline (176 VGPRs / 2 waves per SIMD against 128 / 4 for the online-maximum kernel)
+    static const int pre = [] { const char* e = getenv("VITTF_ATTN_PRESCALED"); return e ? atoi(e) : 0; }();
     { ProfScope ps(VITTF_KERNEL_GEMM, stream);
-      rc = vittf_gemm(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, VITTF_EPI_BIAS_QKV, 0, dt, stream); }
+      rc = vittf_gemm(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, 0,
+                      dt, stream); }
     if (rc) return rc;
     { ProfScope ps(VITTF_KERNEL_ATTENTION, stream);
-      rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, /*q_prescaled=*/1, stream); }
+      rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, pre, stream); }
     if (rc) return rc;
     { ProfScope ps(VITTF_KERNEL_GEMM, stream);
       rc = vittf_gemm(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d, d,
