@@ -212,7 +212,13 @@ int vittf_assemble_sum(const uint16_t* gz, const uint16_t* gy, const uint16_t* g
  * relative coordinates in [-1, 1] in VOLUME dim order (the flip to grid_sample's x,y,z order of infer.py:67
  * happens inside); align_corners=False, zero padding; mode nearest or trilinear ('bilinear').  out fp32 [A][F]. */
 int vittf_sample_features(const void* feat, int32_t feat_is_fp16, int32_t f, int32_t n0, int32_t n1, int32_t n2,
-                          const float* rel, int32_t a, int32_t mode, float* out, void* stream);
+                          const float* rel, int32_t a, int32_t mode, const float* voxel_norm, float* out, void* stream);
+
+/* Per-voxel L2 norm of the F-major fp16 feature volume, clamped like F.normalize's denominator:
+ * out[v] = max(|feat[:, v]|_2, 1e-12), fp32 [nvox].  Passing it as `voxel_norm` to vittf_sample_features /
+ * vittf_similarity makes them operate on F.normalize(feat, dim=0) -- the cosine similarity of
+ * compare_feat_sampling.py:45 / tests/test_vishum.py:12 -- without materialising a normalised copy. */
+int vittf_voxel_norm(const uint16_t* feat, int32_t f, int64_t nvox, float* out, void* stream);
 
 size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox);
 
@@ -222,9 +228,11 @@ size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox);
  *     (big_a_mean != 0: the single-class A > 1024 variant, mean of raw dots first, predict_ntf.py:62-63)
  *     u8     = trunc(255 / (0.99 * max_v sim_c) * sim_c) mod 256 (predict_ntf.py:98-99, x86 wrap-around)
  * then nearest-resized to (o0, o1, o2) (predict_ntf.py:100).  feat fp16 (F, n0, n1, n2) F-major;
- * qf fp32 [A][F]; class_start int32 [classes + 1] on the HOST; out uint8 [classes][o0][o1][o2]. */
+ * qf fp32 [A][F]; class_start int32 [classes + 1] on the HOST; out uint8 [classes][o0][o1][o2].
+ * voxel_norm: NULL (predict_ntf.py semantics: raw dot products) or the vittf_voxel_norm array (every dot divided by
+ * the voxel's norm: cosine similarity against queries sampled with the same array). */
 int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
-                     const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
+                     const int32_t* class_start_host, int32_t classes, int32_t big_a_mean, const float* voxel_norm,
                      int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws, size_t ws_bytes, void* stream);
 
 /* pred = 0; best = 0; for i: mask = sims[i] > thr[i] && sims[i] > best; pred[mask] = i+1; best[mask] = sims[i]

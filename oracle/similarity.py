@@ -64,8 +64,9 @@ def class_similarity(features, qf_class, big_a_mean=False):
     return s.mean(0).reshape(features.shape[1:])
 
 
-def similarity_maps(volume_shape, features, annotations):
+def similarity_maps(volume_shape, features, annotations, normalize=False):
     """predict_ntf.compute_similarities without the bilateral solver.
+    normalize=True applies F.normalize(features, dim=0) first (compare_feat_sampling.py:45, tests/test_vishum.py:12).
 
     volume_shape: (W, H, D) of the full volume; features: (F, W', H', D') fp32;
     annotations: {name: (n, 3) integer voxel coords}.  Returns {name: uint8 (W//2, H//2, D//2)}.
@@ -77,6 +78,8 @@ def similarity_maps(volume_shape, features, annotations):
         return None
     in_dims = tuple(volume_shape[-3:])
     sim_shape = tuple(d // 2 for d in in_dims)
+    if normalize:
+        features = F.normalize(features, dim=0)
     qf = sample_features(features, rel_coords(coords, in_dims), 'bilinear')   # (A, F)
     big = len(annotations) == 1 and coords.shape[0] > 1024
     out, start = {}, 0

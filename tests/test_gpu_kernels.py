@@ -391,3 +391,24 @@ def test_labels_bit_exact_random(gpu):
     assert np.array_equal(vt.assign_labels(sims), osim.assign_labels(sims))
     sims7 = sims + sims[:2]                                        # more maps than thresholds: extra ones are ignored
     assert np.array_equal(vt.assign_labels(sims7), osim.assign_labels(sims7))
+
+
+def test_cosine_similarity_option(gpu):
+    """normalize=True: per-voxel L2 normalisation of the volume (F.normalize(feat, dim=0)) folded into the sampling and
+    similarity kernels through a norm array, against the oracle that normalises the volume explicitly."""
+    g = gen(33)
+    feat = (torch.randn(64, 6, 7, 8, generator=g) * 3 + 0.5 * torch.randn(64, 1, 1, 1, generator=g)).half()
+    feat[:, 0, 0, 0] = 0                                          # a zero voxel: eps clamp of F.normalize
+    shape = (12, 14, 16)
+    ann = {'a': torch.tensor([[2, 3, 4], [7, 7, 7], [11, 13, 15]]), 'b': torch.tensor([[0, 0, 0], [5, 9, 2]])}
+    fd = feat.to(gpu)
+    norms = vt.similarity.voxel_norms(fd).cpu()
+    assert torch.allclose(norms, feat.float().norm(dim=0).clamp_min(1e-12), rtol=1e-6)
+    got = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann, normalize=True)
+    ref = osim.similarity_maps(shape, feat.float(), ann, normalize=True)
+    raw = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann)
+    for k in ann:
+        d = (got[k].int() - ref[k].int()).abs()
+        d = torch.minimum(d, 256 - d)
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, k
+        assert not torch.equal(got[k], raw[k])                   # and it is not the un-normalised map

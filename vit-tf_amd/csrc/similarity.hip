@@ -22,7 +22,7 @@ __device__ __forceinline__ float feat_at(const void* feat, int64_t idx) {
 template <bool HALF>
 __global__ __launch_bounds__(256) void sample_kernel(const void* __restrict__ feat, int f, int n0, int n1, int n2,
                                                      const float* __restrict__ rel, int na, int mode,
-                                                     float* __restrict__ out) {
+                                                     const float* __restrict__ vnorm, float* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)na * f) return;
   const int a = (int)(e / f), ff = (int)(e - (int64_t)a * f);
@@ -37,8 +37,11 @@ __global__ __launch_bounds__(256) void sample_kernel(const void* __restrict__ fe
   float res = 0.f;
   if (mode == VITTF_SAMPLE_NEAREST) {
     const int x = (int)rintf(ix), y = (int)rintf(iy), z = (int)rintf(iz);
-    if (x >= 0 && x < n2 && y >= 0 && y < n1 && z >= 0 && z < n0)
-      res = feat_at<HALF>(feat, fbase + z * plane + (int64_t)y * n2 + x);
+    if (x >= 0 && x < n2 && y >= 0 && y < n1 && z >= 0 && z < n0) {
+      const int64_t vox = z * plane + (int64_t)y * n2 + x;
+      res = feat_at<HALF>(feat, fbase + vox);
+      if (vnorm) res = res / vnorm[vox];           // F.normalize(feat, dim=0): v / max(|v|, eps)
+    }
   } else {
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
     const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
@@ -53,11 +56,42 @@ __global__ __launch_bounds__(256) void sample_kernel(const void* __restrict__ fe
         for (int cx = 0; cx < 2; ++cx) {
           const int x = x0 + cx, y = y0 + cy, z = z0 + cz;
           const float wgt = (cx ? wx1 : wx0) * (cy ? wy1 : wy0) * (cz ? wz1 : wz0);
-          if (x >= 0 && x < n2 && y >= 0 && y < n1 && z >= 0 && z < n0)
-            res = __fadd_rn(res, __fmul_rn(feat_at<HALF>(feat, fbase + z * plane + (int64_t)y * n2 + x), wgt));  // unfused, like the CPU op
+          if (x >= 0 && x < n2 && y >= 0 && y < n1 && z >= 0 && z < n0) {
+            const int64_t vox = z * plane + (int64_t)y * n2 + x;
+            float val = feat_at<HALF>(feat, fbase + vox);
+            if (vnorm) val = val / vnorm[vox];
+            res = __fadd_rn(res, __fmul_rn(val, wgt));  // unfused, like the CPU op
+          }
         }
   }
   out[e] = res;
+}
+
+// ---------------------------------------------------------------- per-voxel L2 norm (cosine similarity)
+// max(|feat[:, v]|_2, 1e-12): the denominator of F.normalize(feat, dim=0) (compare_feat_sampling.py:45,
+// tests/test_vishum.py:12).  Keeping the norms (1 MB) instead of a normalised fp32 copy of the volume (403 MB)
+// leaves the similarity kernel on the fp16 volume: (sum_f x_f q_f) / |x| instead of sum_f (x_f / |x|) q_f.
+__global__ __launch_bounds__(256) void voxel_norm_kernel(const unsigned short* __restrict__ feat, int f, int64_t nvox,
+                                                         float* __restrict__ out) {
+  const int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (v0 >= nvox) return;
+  const bool vec = (v0 + 2 <= nvox) && ((nvox & 1) == 0);
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+  for (int ff = 0; ff < f; ++ff) {
+    const unsigned short* p = feat + (int64_t)ff * nvox + v0;
+    float x0, x1 = 0.f;
+    if (vec) {
+      const unsigned raw = *reinterpret_cast<const unsigned*>(p);
+      x0 = f16bits_to_f32((unsigned short)(raw & 0xffff)); x1 = f16bits_to_f32((unsigned short)(raw >> 16));
+    } else {
+      x0 = f16bits_to_f32(p[0]);
+      if (v0 + 1 < nvox) x1 = f16bits_to_f32(p[1]);
+    }
+    s0 = fmaf(x0, x0, s0); s1 = fmaf(x1, x1, s1);
+  }
+  out[v0] = fmaxf(sqrtf(s0), 1e-12f);
+  if (v0 + 1 < nvox) out[v0 + 1] = fmaxf(sqrtf(s1), 1e-12f);
 }
 
 // ---------------------------------------------------------------- similarity
@@ -92,7 +126,8 @@ __device__ __forceinline__ float thresh_pow(float s) {
 template <bool BIG>
 __global__ __launch_bounds__(256) void sim_accumulate(const unsigned short* __restrict__ feat, int f, int64_t nvox,
                                                       const float* __restrict__ qf_t, SimChunk ch,
-                                                      float* __restrict__ sim, unsigned* __restrict__ maxbits) {
+                                                      const float* __restrict__ vnorm, float* __restrict__ sim,
+                                                      unsigned* __restrict__ maxbits) {
   const int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VPT;
   float acc[ACH][VPT];
 #pragma unroll
@@ -120,6 +155,14 @@ __global__ __launch_bounds__(256) void sim_accumulate(const unsigned short* __re
 #pragma unroll
         for (int j = 0; j < VPT; ++j) acc[a][j] = fmaf(x[j], qa, acc[a][j]);
       }
+    }
+  }
+  if (vnorm) {     // cosine similarity: the volume is normalised per voxel (the queries were sampled from it normalised)
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const float nv = (v0 + j < nvox) ? vnorm[v0 + j] : 1.f;
+#pragma unroll
+      for (int a = 0; a < ACH; ++a) acc[a][j] = acc[a][j] / nv;
     }
   }
   // per-class reduction over the chunk's annotations
@@ -205,16 +248,25 @@ __global__ __launch_bounds__(256) void labels_kernel(const unsigned char* __rest
 }  // namespace
 
 extern "C" int vittf_sample_features(const void* feat, int32_t feat_is_fp16, int32_t f, int32_t n0, int32_t n1, int32_t n2,
-                                     const float* rel, int32_t a, int32_t mode, float* out, void* stream) {
+                                     const float* rel, int32_t a, int32_t mode, const float* voxel_norm, float* out,
+                                     void* stream) {
   if (!feat || !rel || !out || f <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0 || a <= 0) return VITTF_ERR_INVALID_ARG;
   if (mode != VITTF_SAMPLE_NEAREST && mode != VITTF_SAMPLE_TRILINEAR) return VITTF_ERR_INVALID_ARG;
   const int64_t total = (int64_t)a * f;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
   if (feat_is_fp16)
-    hipLaunchKernelGGL((sample_kernel<true>), dim3(blocks), dim3(256), 0, st, feat, f, n0, n1, n2, rel, a, mode, out);
+    hipLaunchKernelGGL((sample_kernel<true>), dim3(blocks), dim3(256), 0, st, feat, f, n0, n1, n2, rel, a, mode, voxel_norm, out);
   else
-    hipLaunchKernelGGL((sample_kernel<false>), dim3(blocks), dim3(256), 0, st, feat, f, n0, n1, n2, rel, a, mode, out);
+    hipLaunchKernelGGL((sample_kernel<false>), dim3(blocks), dim3(256), 0, st, feat, f, n0, n1, n2, rel, a, mode, voxel_norm, out);
+  return vittf_check_launch();
+}
+
+extern "C" int vittf_voxel_norm(const uint16_t* feat, int32_t f, int64_t nvox, float* out, void* stream) {
+  if (!feat || !out || f <= 0 || nvox <= 0 || ((uintptr_t)feat & 3) != 0) return VITTF_ERR_INVALID_ARG;
+  const int64_t threads = (nvox + 1) / 2;
+  hipLaunchKernelGGL(voxel_norm_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat, f, nvox,
+                     out);
   return vittf_check_launch();
 }
 
@@ -227,8 +279,9 @@ extern "C" size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox
 }
 
 extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
-                                const int32_t* class_start_host, int32_t classes, int32_t big_a_mean, int32_t o0,
-                                int32_t o1, int32_t o2, uint8_t* out, void* ws, size_t ws_bytes, void* stream) {
+                                const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
+                                const float* voxel_norm, int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws,
+                                size_t ws_bytes, void* stream) {
   if (!feat || !qf || !class_start_host || !out || !ws) return VITTF_ERR_INVALID_ARG;
   if (f <= 0 || f > 4096 || n0 <= 0 || n1 <= 0 || n2 <= 0 || classes <= 0 || o0 <= 0 || o1 <= 0 || o2 <= 0)
     return VITTF_ERR_INVALID_ARG;
@@ -274,9 +327,9 @@ extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int
     }
     hipLaunchKernelGGL(transpose_queries, dim3((f * ACH + 255) / 256), dim3(256), 0, st, qf, f, a0, n, qf_t);
     if (big_a_mean)
-      hipLaunchKernelGGL((sim_accumulate<true>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, sim, maxbits);
+      hipLaunchKernelGGL((sim_accumulate<true>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, sim, maxbits);
     else
-      hipLaunchKernelGGL((sim_accumulate<false>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, sim, maxbits);
+      hipLaunchKernelGGL((sim_accumulate<false>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, sim, maxbits);
     a0 += n;
   }
   const int64_t total_out = (int64_t)classes * o0 * o1 * o2;

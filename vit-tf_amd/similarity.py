@@ -23,6 +23,15 @@ def _device_features(features, device):
     return t.to(device=device, dtype=torch.float16).contiguous()
 
 
+def voxel_norms(feat):
+    """max(|feat[:, v]|, 1e-12) per voxel of a contiguous fp16 (F, n0, n1, n2) device tensor: fp32 (n0, n1, n2)."""
+    lib = _lib.require_device()
+    out = torch.empty(feat.shape[1:], dtype=torch.float32, device=feat.device)
+    _lib.check(lib.vittf_voxel_norm(_lib.ptr(feat), feat.shape[0], out.numel(), _lib.ptr(out), _lib.stream_ptr()),
+               'vittf_voxel_norm')
+    return out
+
+
 def sample_features3d(feat_vol, rel_coords, mode='nearest'):
     """infer.py:48-72.  feat_vol ([M,] F, W, H, D); rel_coords ([M,] C, A, 3) in [-1, 1], volume dim
     order.  Returns ([M,] C, A, F) on the device, fp32.  Unlike the reference it does not mutate `rel_coords`."""
@@ -44,16 +53,18 @@ def sample_features3d(feat_vol, rel_coords, mode='nearest'):
         f = f.to(dev, torch.float16 if is_half else torch.float32).contiguous()
         rel = rc[i].reshape(-1, 3).to(dev, torch.float32).contiguous()
         _lib.check(lib.vittf_sample_features(_lib.ptr(f), int(is_half), f.shape[0], f.shape[1], f.shape[2], f.shape[3],
-                                             _lib.ptr(rel), rel.shape[0], _lib.SAMPLE_MODES[mode], _lib.ptr(out[i]),
+                                             _lib.ptr(rel), rel.shape[0], _lib.SAMPLE_MODES[mode], None, _lib.ptr(out[i]),
                                              _lib.stream_ptr()), 'vittf_sample_features')
     return out
 
 
-def compute_similarities(volume, features, annotations, bilateral_solver=False, device=None):
+def compute_similarities(volume, features, annotations, bilateral_solver=False, device=None, normalize=False):
     """predict_ntf.py:24-101 (bilateral_solver=False).  volume: (W, H, D) array/tensor (only its shape is
     used); features: (F, W', H', D'); annotations: {name: (n, 3) voxel coords}.
     Returns {name: uint8 CPU tensor (W//2, H//2, D//2)}; None when there is nothing to query
-    (predict_ntf.py:51-55).  Classes with zero annotations are skipped."""
+    (predict_ntf.py:51-55).  Classes with zero annotations are skipped.
+    normalize=True: cosine similarity -- the volume is L2-normalised per voxel first, as
+    compare_feat_sampling.py:45 and tests/test_vishum.py:12 do (predict_ntf.py itself does not)."""
     if bilateral_solver:
         raise NotImplementedError('bilateral solver post-process is outside the round-1 hot path (SURVEY.md 8f-1)')
     if len(annotations) == 0:
@@ -73,9 +84,10 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
     ext = torch.tensor([list(in_dims)], dtype=torch.float32)
     rel = ((coords.float() + 0.5) / ext * 2.0 - 1.0).to(dev).contiguous()
     a_total = rel.shape[0]
+    vnorm = voxel_norms(feat) if normalize else None
     qf = torch.empty((a_total, f), dtype=torch.float32, device=dev)
     _lib.check(lib.vittf_sample_features(_lib.ptr(feat), 1, f, n0, n1, n2, _lib.ptr(rel), a_total,
-                                         _lib.SAMPLE_MODES['bilinear'], _lib.ptr(qf), _lib.stream_ptr()),
+                                         _lib.SAMPLE_MODES['bilinear'], _lib.ptr(vnorm), _lib.ptr(qf), _lib.stream_ptr()),
                'vittf_sample_features')
 
     counts = [int(torch.as_tensor(annotations[k]).reshape(-1, 3).shape[0]) for k in names]
@@ -86,7 +98,7 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     out = torch.empty((nclass, *sim_shape), dtype=torch.uint8, device=dev)
     _lib.check(lib.vittf_similarity(_lib.ptr(feat), f, n0, n1, n2, _lib.ptr(qf),
-                                    starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big,
+                                    starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big, _lib.ptr(vnorm),
                                     sim_shape[0], sim_shape[1], sim_shape[2], _lib.ptr(out), _lib.ptr(ws), ws_bytes,
                                     _lib.stream_ptr()), 'vittf_similarity')
     host = out.cpu()
