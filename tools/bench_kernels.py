@@ -56,6 +56,23 @@ def main():
             fl = 2 * rows * n * k
             byts = rows * k * 2 + n * k * 2 + rows * n * (8 if epi == 2 else 2)
             print(f'gemm {name:9s} [{rows}x{k}]x[{n}x{k}]^T: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s   {byts / ms / 1e6:.0f} GB/s algorithmic')
+    if 'stock' in what:   # the same shapes on the stock ROCm libraries (hipBLASLt, SDPA): what unmodified torch would do here
+        import torch.nn.functional as F
+        for name, n, k in (('qkv', 3 * d, d), ('proj', d, d), ('fc1', 4 * d, d), ('fc2', d, 4 * d)):
+            a = torch.randn(rows, k, generator=g).to(TDT[dt]).to(dev)
+            w = (torch.randn(n, k, generator=g) / k ** 0.5).to(TDT[dt]).to(dev)
+            bias = torch.randn(n, generator=g).to(TDT[dt]).to(dev)
+            ms = timeit(lambda: F.linear(a, w, bias))
+            print(f'stock linear {name:5s} [{rows}x{k}]x[{n}x{k}]^T (16-bit out, no epilogue): {ms:.3f} ms  {2 * rows * n * k / ms / 1e9:.1f} TFLOP/s')
+        q = torch.randn(batch, heads, tokens, 64, generator=g).to(TDT[dt]).to(dev)
+        kk = torch.randn(batch, heads, tokens, 64, generator=g).to(TDT[dt]).to(dev)
+        v = torch.randn(batch, heads, tokens, 64, generator=g).to(TDT[dt]).to(dev)
+        try:
+            ms = timeit(lambda: F.scaled_dot_product_attention(q, kk, v))
+            fl = batch * 4 * tokens * tokens * d
+            print(f'stock SDPA batch {batch} N {tokens}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s')
+        except Exception as e:  # noqa: BLE001
+            print('stock SDPA failed:', e)
     if 'mlp' in what:
         hh = torch.randn(rows, d, generator=g).to(TDT[dt]).to(dev)
         w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(dev)
