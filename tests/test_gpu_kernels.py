@@ -53,7 +53,7 @@ def _gemm_inputs(rows, n, k, dt, seed):
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('rows,n,k', [(1, 128, 64), (100, 128, 128), (128, 384, 384), (300, 1152, 384),
-                                      (257, 384, 1536), (8194, 1536, 384)])
+                                      (257, 384, 1536), (8194, 1536, 384), (19205, 1152, 384)])
 def test_gemm_bias_and_gelu(gpu, dt, rows, n, k):
     lib = _lib.load()
     a, w, bias, ref = _gemm_inputs(rows, n, k, dt, rows + n + k)
@@ -69,7 +69,7 @@ def test_gemm_bias_and_gelu(gpu, dt, rows, n, k):
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-@pytest.mark.parametrize('rows,n,k', [(3, 128, 64), (515, 384, 384), (200, 384, 1536)])
+@pytest.mark.parametrize('rows,n,k', [(3, 128, 64), (515, 384, 384), (200, 384, 1536), (33000, 384, 384)])
 def test_gemm_residual(gpu, dt, rows, n, k):
     lib = _lib.load()
     a, w, bias, ref = _gemm_inputs(rows, n, k, dt, rows * 3 + n)

@@ -266,6 +266,9 @@ int launch_gemm(const void* a, const void* w, const float* bias, void* out, int6
 
 }  // namespace
 
+int vittf_gemm_ws(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
+                  int32_t epilogue, int32_t dtype, hipStream_t st);   // gemm_ws.hip; 1 = not covered
+
 extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n,
                           int32_t k, int32_t epilogue, int32_t tokens, int32_t dtype, void* stream) {
   if (!a || !w || !bias || !out || rows <= 0 || n <= 0 || k <= 0) return VITTF_ERR_INVALID_ARG;
@@ -273,6 +276,12 @@ extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void*
   if (epilogue == VITTF_EPI_KFEAT && tokens < 2) return VITTF_ERR_INVALID_ARG;
   if (rows / BM + 1 > (1 << 20)) return VITTF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
+  // K = 384 (ViT-S): weight-stationary kernel (VITTF_GEMM_WS=0 keeps everything on the tiled kernel below)
+  static const int use_ws = [] { const char* e = getenv("VITTF_GEMM_WS"); return e ? atoi(e) : 1; }();
+  if (use_ws) {
+    const int rc = vittf_gemm_ws(a, w, bias, out, rows, n, k, epilogue, dtype, st);
+    if (rc != 1) return rc;
+  }
   if (dtype == VITTF_BF16) return launch_gemm<VITTF_BF16>(a, w, bias, out, rows, n, k, epilogue, tokens, st);
   if (dtype == VITTF_FP16) return launch_gemm<VITTF_FP16>(a, w, bias, out, rows, n, k, epilogue, tokens, st);
   return VITTF_ERR_INVALID_ARG;

@@ -83,6 +83,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// exact-erf GELU  x Phi(x) = x - 0.5 x erfc(|x| / sqrt 2)  (x >= 0),  0.5 x erfc(|x| / sqrt 2)  (x < 0), with
+// erfc(z) = 2^-Q(z), Q a degree-5 polynomial without constant term (weighted minimax fit on [0, 4.2], monotone
+// beyond): |gelu error| <= 1.4e-6 absolute over all x (fit + check: tools/fit_gelu.py), far below the 16-bit
+// rounding of the result.  One v_exp_f32 and no reciprocal: 44 issue cycles per wave against 68 for the
+// Abramowitz-Stegun 7.1.26 form (the epilogue of fc1 is VALU-bound: 201 M activations per launch).
+__device__ __forceinline__ float gelu_poly(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  float p = fmaf(-0.002965539f, z, 0.0296764448f);
+  p = fmaf(p, z, -0.148780614f);
+  p = fmaf(p, z, -0.918451846f);
+  p = fmaf(p, z, -1.6278975f);
+  const float r = x * __builtin_amdgcn_exp2f(fmaf(p, z, -1.0f));   // 0.5 x erfc(z)
+  return x >= 0.f ? x - r : r;
+}
+
 static inline int vittf_check_launch() {
   return hipGetLastError() == hipSuccess ? VITTF_OK : VITTF_ERR_LAUNCH;
 }
