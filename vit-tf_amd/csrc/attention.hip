@@ -185,8 +185,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void attn_kernel(const unsigned s
   const unsigned short* base = qkv + (int64_t)b * tokens * ld;
 
   // buffer descriptor over this slice's qkv rows: loads past the last token return 0 (no clamping VALU)
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((int64_t)tokens * ld * 2), 0x00020000);
+  const i32x4_t rsrc = lds_dma_rsrc(base, (unsigned)((int64_t)tokens * ld * 2));
 
   // ---- Q fragments (B operand): lane holds Q[row l31][16 s + 8 h .. +7] ----
   const int qrow = qt * QT + wave * 32 + l31;
@@ -219,14 +218,16 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void attn_kernel(const unsigned s
     voff_v1 = v_src(256 + tid);
   }
   const int tile_stride = KT * ld * 2;
-  char* const dma_dst = smem + ((tid & ~63) << 4);   // wave-uniform; the hardware adds lane * 16
+  // wave-uniform LDS byte address; the hardware adds lane * 16.  (asm pieces, see lds_dma16: with the builtin hipcc
+  // put s_waitcnt vmcnt(0) in front of the V reads in the middle of every tile.)
+  const unsigned dma_dst = (unsigned)(size_t)LDS_PTR(smem) + (__builtin_amdgcn_readfirstlane(tid & ~63) << 4);
 #define ATTN_STAGE_TILE(t, BUFI)                                                                              \
   {                                                                                                           \
     const int so_ = (t) * tile_stride;                                                                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dma_dst + (BUFI) * BUF_BYTES), 16, voff_k0, so_, 0, 0);        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dma_dst + (BUFI) * BUF_BYTES + 4096), 16, voff_k1, so_, 0, 0); \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES), 16, voff_v0, so_, 0, 0);        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES + 4096), 16, voff_v1, so_, 0, 0); \
+    lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES, voff_k0, so_);                                                 \
+    lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + 4096, voff_k1, so_);                                          \
+    lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES, voff_v0, so_);                                 \
+    lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES + 4096, voff_v1, so_);                          \
   }
 
   // ---- per-lane LDS read bases (see tile_off / v_off: the kt, s2, dvt, jj and buffer terms are immediates) ----

@@ -42,37 +42,20 @@ constexpr int WCBYTES = WBM * WCS;
 // needs two source offsets (chunk c, chunk c + 128) and the rest is scalar.  The tile is addressed through a buffer
 // descriptor that starts at its first row and ends with the matrix: rows past the end read as zeros (and are never
 // stored).  (Not a template: hipcc's host pass drops function templates whose bodies name the descriptor type.)
-typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-
-// One LDS-DMA piece (64 lanes x 16 B -> 1 KB at LDS address lds_addr, lane-linear).  Written as asm so that hipcc
-// does not know about it: it orders every later ds_write / ds_read against an outstanding LDS-DMA it knows of with
-// vmcnt(0), which would drain the prefetch and the stores.  Completion is waited for explicitly (counted vmcnt in
-// the loader waves, then the workgroup barrier).  rsrc / lds_addr / soff are SALU-computed (no VALU->SGPR hazard).
-__device__ __forceinline__ void ws_dma16(i32x4_t rsrc, unsigned lds_addr, int voff, int soff) {
-  unsigned keep;   // M0 is saved and restored: hipcc does not accept it as a clobber
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-
 __device__ __forceinline__ void ws_stage(const unsigned short* __restrict__ A, int64_t m0, int64_t rows, int wave,
                                          int voff_a, int voff_b, unsigned tile_lds) {
   const int64_t left = (rows - m0) * (WK * 2);
-  const uint64_t base = reinterpret_cast<uint64_t>(A + m0 * WK);
-  i32x4_t rsrc;
-  rsrc[0] = (int)(unsigned)base;
-  rsrc[1] = (int)((unsigned)(base >> 32) & 0xffffu);
-  rsrc[2] = (int)(left < WABYTES ? left : WABYTES);
-  rsrc[3] = 0x00020000;
+  const i32x4_t rsrc = lds_dma_rsrc(A + m0 * WK, (unsigned)(left < WABYTES ? left : WABYTES));
   if (wave < 4) {
     const unsigned dst = tile_lds + wave * 1024;    // + lane * 16 by the hardware
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ws_dma16(rsrc, dst + i * WSUB, voff_a, i * 128);
+    for (int i = 0; i < 4; ++i) lds_dma16(rsrc, dst + i * WSUB, voff_a, i * 128);
   } else {
     const unsigned dst = tile_lds + 4 * WSUB + (wave - 4) * 1024;
-    ws_dma16(rsrc, dst, voff_a, 4 * 128);
-    ws_dma16(rsrc, dst + 2048, voff_b, 4 * 128);
-    ws_dma16(rsrc, dst + WSUB, voff_a, 5 * 128);
-    ws_dma16(rsrc, dst + WSUB + 2048, voff_b, 5 * 128);
+    lds_dma16(rsrc, dst, voff_a, 4 * 128);
+    lds_dma16(rsrc, dst + 2048, voff_b, 4 * 128);
+    lds_dma16(rsrc, dst + WSUB, voff_a, 5 * 128);
+    lds_dma16(rsrc, dst + WSUB + 2048, voff_b, 5 * 128);
   }
 }
 

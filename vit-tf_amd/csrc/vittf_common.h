@@ -98,6 +98,29 @@ __device__ __forceinline__ float gelu_poly(float x) {
   return x >= 0.f ? x - r : r;
 }
 
+// ---- LDS-DMA hidden from hipcc -------------------------------------------------------------------------------
+// One piece: 64 lanes x 16 B -> 1 KB at LDS byte address lds_addr (lane-linear), fetched through a buffer descriptor
+// (bytes past num_records read as zeros).  hipcc orders every later ds_read / ds_write against an outstanding
+// LDS-DMA it knows of (the builtins) with s_waitcnt vmcnt(0) -- it cannot tell which LDS bytes the DMA writes --
+// which drains the prefetch (and, vmcnt retiring in issue order, every store before it).  Written as asm, the
+// piece is invisible to that bookkeeping: the kernel waits for it itself (counted vmcnt, then a barrier).
+// rsrc, lds_addr and soff must be wave-uniform and SALU-computed (no VALU->SGPR hazard handling inside asm).
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+__device__ __forceinline__ i32x4_t lds_dma_rsrc(const void* base_ptr, unsigned bytes) {
+  const uint64_t base = reinterpret_cast<uint64_t>(base_ptr);
+  i32x4_t r;
+  r[0] = (int)(unsigned)base;
+  r[1] = (int)((unsigned)(base >> 32) & 0xffffu);
+  r[2] = (int)bytes;
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void lds_dma16(i32x4_t rsrc, unsigned lds_addr, int voff, int soff) {
+  unsigned keep;   // M0 is saved and restored: hipcc does not accept it as a clobber
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 static inline int vittf_check_launch() {
   return hipGetLastError() == hipSuccess ? VITTF_OK : VITTF_ERR_LAUNCH;
 }
