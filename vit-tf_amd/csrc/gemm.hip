@@ -37,22 +37,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erfv);
 }
 
-// issue the LDS-DMA of one [128][64] operand tile: 1024 16-byte chunks, 4 per thread
+// issue the LDS-DMA of one [128][64] operand tile: 1024 16-byte chunks, 4 per thread (asm pieces, see lds_dma16:
+// with the builtin, hipcc drains vmcnt(0) before the fragment reads of the tile being multiplied, which is what
+// made the two-stage pipeline slower than the single stage)
 template <typename T>
 __device__ __forceinline__ void stage_tile(const T* __restrict__ src, int64_t ld, int64_t row0, int64_t row_max,
-                                           int k0, char* lds_tile, int tid) {
+                                           int k0, unsigned lds_tile, int tid, const int (&voff)[4]) {
+  // descriptor over the tile's rows [row0, min(row0 + 127, row_max)]: rows past the end read as zeros (never stored)
+  const int64_t nrows = row_max - row0 + 1 < 128 ? row_max - row0 + 1 : 128;
+  const i32x4_t rsrc = lds_dma_rsrc(src + row0 * ld, (unsigned)(nrows * ld * 2));
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = i * 256 + tid;
-    int r, c;
-    tile_pos(q, r, c);
-    int64_t row = row0 + r;
-    row = row < row_max ? row : row_max;  // clamp: rows past the end re-read the last row, never stored
-    const T* g = src + row * ld + k0 + c * 8;
-    // wave-uniform LDS base; the hardware adds lane * 16
-    char* dst = lds_tile + ((i * 256 + (tid & ~63)) << 4);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(dst), 16, 0, 0);
-  }
+  for (int i = 0; i < 4; ++i) lds_dma16(rsrc, lds_tile + i * 4096, voff[i], k0 * 2);
 }
 
 template <int DT, int EPI, int NSTAGE>
@@ -81,6 +76,14 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_kernel(const un
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = k / BK;
+  int voff[4];   // LDS-DMA source offsets: chunk q = i * 256 + tid of a tile image <- (row, 16-byte chunk) = tile_pos(q)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r, c;
+    tile_pos(i * 256 + tid, r, c);
+    voff[i] = (r * k + c * 8) * 2;
+  }
+  const unsigned lds_wave = (unsigned)(size_t)LDS_PTR(smem) + (__builtin_amdgcn_readfirstlane(tid & ~63) << 4);
   auto compute_tile = [&](const char* a_t, const char* w_t) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -100,24 +103,24 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_kernel(const un
   if constexpr (NSTAGE == 1) {
     // one 32 KB stage, four workgroups per CU: the other workgroups' MFMAs cover this one's load latency
     for (int t = 0; t < nk; ++t) {
-      stage_tile(A, k, m0, rows - 1, t * BK, smem, tid);
-      stage_tile(W, k, n0, n - 1, t * BK, smem + TILE_BYTES, tid);
+      stage_tile(A, k, m0, rows - 1, t * BK, lds_wave, tid, voff);
+      stage_tile(W, k, n0, n - 1, t * BK, lds_wave + TILE_BYTES, tid, voff);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       compute_tile(smem, smem + TILE_BYTES);
       __syncthreads();
     }
   } else {
-    stage_tile(A, k, m0, rows - 1, 0, smem, tid);
-    stage_tile(W, k, n0, n - 1, 0, smem + TILE_BYTES, tid);
+    stage_tile(A, k, m0, rows - 1, 0, lds_wave, tid, voff);
+    stage_tile(W, k, n0, n - 1, 0, lds_wave + TILE_BYTES, tid, voff);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
       char* cur = smem + (t & 1) * 2 * TILE_BYTES;
       if (t + 1 < nk) {
-        char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-        stage_tile(A, k, m0, rows - 1, (t + 1) * BK, nxt, tid);
-        stage_tile(W, k, n0, n - 1, (t + 1) * BK, nxt + TILE_BYTES, tid);
+        const unsigned nxt = lds_wave + ((t + 1) & 1) * 2 * TILE_BYTES;
+        stage_tile(A, k, m0, rows - 1, (t + 1) * BK, nxt, tid, voff);
+        stage_tile(W, k, n0, n - 1, (t + 1) * BK, nxt + TILE_BYTES, tid, voff);
       }
       compute_tile(cur, cur + TILE_BYTES);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
