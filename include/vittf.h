@@ -235,6 +235,43 @@ int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, in
                      const int32_t* class_start_host, int32_t classes, int32_t big_a_mean, const float* voxel_norm,
                      int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws, size_t ws_bytes, void* stream);
 
+/* The fp32 per-class maps of vittf_similarity before quantisation and resizing: maps_out fp32 [classes][n0*n1*n2]
+ * (predict_ntf.py:71-72; the input of the bilateral-solver branch :73-96).  ws: the first two regions of
+ * vittf_similarity_workspace_bytes() suffice. */
+int vittf_similarity_maps_f32(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
+                              const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
+                              const float* voxel_norm, float* maps_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- 3-D bilateral solver post-process (bilateral_solver3d.py, predict_ntf.py:73-96) ---------- */
+typedef struct vittf_bilateral_params {
+  double sigma_spatial;        /* grid_params['sigma_spatial'] (predict_ntf.py:75-79: 7) */
+  double lam;                  /* bs_params_default (bilateral_solver3d.py:162-167): 256 */
+  double a_diag_min;           /* 1e-5 */
+  double cg_tol;               /* 1e-5, relative to |b| (scipy cg rtol) */
+  int32_t cg_maxiter;          /* 25 */
+  int32_t bistochastize_iters; /* 10 (bilateral_solver3d.py:107) */
+  int32_t pad;                 /* crop_pad(..., pad=2) (predict_ntf.py:90) */
+  float crop_threshold;        /* crop_pad(..., thresh=0.1) */
+} vittf_bilateral_params;
+
+/* luma_bins = 1 + the largest luma bin; 0 = unsupported size. */
+size_t vittf_bilateral_workspace_bytes(int32_t o0, int32_t o1, int32_t o2, double sigma_spatial, int32_t luma_bins);
+
+/* One class of predict_ntf.py:80-94: volume (v0, v1, v2) fp32 and the class map sim_in (n0, n1, n2) fp32 are resized
+ * (trilinear) to (o0, o1, o2); the volume becomes the uint8 grey reference (min-max); the box where sim > crop_threshold
+ * (+ pad) is refined by the bilateral solver with the Sobel confidence and written back.  sim_out: fp32 (o0, o1, o2).
+ * [host] luma_bin_host[256]: bilateral-space luma bin of each grey level, (rgb2yuv(v, v, v)[0] / sigma_luma).astype(int)
+ * (bilateral_solver3d.py:19-20, 47); the chroma bins are constant for a grey reference and drop out.
+ * [host] info_host (nullable): {vertices, voxels in the crop box}; {0, 0} when nothing exceeds the threshold (the map is
+ * then returned unrefined; the reference raises in that case).  Synchronises the stream twice (box, vertex count). */
+int vittf_bilateral_refine(const float* sim_in, int32_t n0, int32_t n1, int32_t n2, const float* volume, int32_t v0,
+                           int32_t v1, int32_t v2, int32_t o0, int32_t o1, int32_t o2, const int32_t* luma_bin_host,
+                           int32_t luma_bins, const vittf_bilateral_params* prm, float* sim_out, int32_t* info_host,
+                           void* ws, size_t ws_bytes, void* stream);
+
+/* (255 / (0.99 * max(sim)) * sim).to(uint8) with the x86 wrap-around (predict_ntf.py:95-96).  max_scratch: 4 device bytes. */
+int vittf_quantize_wrap_u8(const float* sim, int64_t n, uint8_t* out, float* max_scratch, void* stream);
+
 /* pred = 0; best = 0; for i: mask = sims[i] > thr[i] && sims[i] > best; pred[mask] = i+1; best[mask] = sims[i]
  * sims uint8 [classes][n]; thr int32 [classes] on the HOST (= int(t*255), predict_ntf.py:212); labels uint8 [n]. */
 int vittf_assign_labels(const uint8_t* sims, int32_t classes, int64_t n, const int32_t* thr_host, uint8_t* labels,

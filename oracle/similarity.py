@@ -64,9 +64,27 @@ def class_similarity(features, qf_class, big_a_mean=False):
     return s.mean(0).reshape(features.shape[1:])
 
 
-def similarity_maps(volume_shape, features, annotations, normalize=False):
-    """predict_ntf.compute_similarities without the bilateral solver.
+def class_maps_fp32(volume_shape, features, annotations, normalize=False):
+    """Per-class fp32 maps at the feature-grid resolution, before quantisation (predict_ntf.py:52-72)."""
+    coords = torch.cat([torch.as_tensor(v) for v in annotations.values()])
+    in_dims = tuple(volume_shape[-3:])
+    if normalize:
+        features = F.normalize(features, dim=0)
+    qf = sample_features(features, rel_coords(coords, in_dims), 'bilinear')   # (A, F)
+    big = len(annotations) == 1 and coords.shape[0] > 1024
+    out, start = {}, 0
+    for name, v in annotations.items():
+        n = torch.as_tensor(v).shape[0]
+        out[name] = class_similarity(features, qf[start:start + n], big_a_mean=big)
+        start += n
+    return out
+
+
+def similarity_maps(volume_shape, features, annotations, normalize=False, volume=None):
+    """predict_ntf.compute_similarities.
     normalize=True applies F.normalize(features, dim=0) first (compare_feat_sampling.py:45, tests/test_vishum.py:12).
+    volume: the (W, H, D) volume itself -> the bilateral-solver branch (predict_ntf.py:73-96, oracle/bilateral.py);
+    None -> the plain branch (quantise, then nearest resize; predict_ntf.py:97-100).
 
     volume_shape: (W, H, D) of the full volume; features: (F, W', H', D') fp32;
     annotations: {name: (n, 3) integer voxel coords}.  Returns {name: uint8 (W//2, H//2, D//2)}.
@@ -76,19 +94,16 @@ def similarity_maps(volume_shape, features, annotations, normalize=False):
     coords = torch.cat([torch.as_tensor(v) for v in annotations.values()])
     if coords.numel() == 0:
         return None
-    in_dims = tuple(volume_shape[-3:])
-    sim_shape = tuple(d // 2 for d in in_dims)
-    if normalize:
-        features = F.normalize(features, dim=0)
-    qf = sample_features(features, rel_coords(coords, in_dims), 'bilinear')   # (A, F)
-    big = len(annotations) == 1 and coords.shape[0] > 1024
-    out, start = {}, 0
-    for name, v in annotations.items():
-        n = torch.as_tensor(v).shape[0]
-        sim = class_similarity(features, qf[start:start + n], big_a_mean=big)
-        start += n
-        q, _ = quantize_u8(sim)
-        out[name] = F.interpolate(q[None, None], sim_shape, mode='nearest')[0, 0]
+    sim_shape = tuple(d // 2 for d in tuple(volume_shape[-3:]))
+    out = {}
+    for name, sim in class_maps_fp32(volume_shape, features, annotations, normalize).items():
+        if volume is not None:
+            from . import bilateral
+            q, _ = quantize_u8(bilateral.refine_similarity(sim, volume, sim_shape))
+            out[name] = q
+        else:
+            q, _ = quantize_u8(sim)
+            out[name] = F.interpolate(q[None, None], sim_shape, mode='nearest')[0, 0]
     return out
 
 

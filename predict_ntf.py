@@ -3,8 +3,8 @@
 Same function and CLI surface as /root/reference/predict_ntf.py (compute_similarities :24-101, flags
 :105-112, directory contract :119-172, label assignment :203-215, outputs :216, :249-250); the query
 sampling, the voxel x query contraction, threshold / power / class mean, quantisation and the label
-arg-max run in libvittf's HIP kernels (``--gpu`` is implied: there is no CPU path).  The bilateral-solver
-post-process (``--bilateral-solver``) is not part of this build yet and exits with 1.
+arg-max run in libvittf's HIP kernels (``--gpu`` is implied: there is no CPU path), and so does the bilateral-solver
+post-process (``--bilateral-solver``, bilateral.hip).
 """
 import json
 import sys
@@ -80,10 +80,6 @@ def main(argv=None):
     parser.add_argument('--sampling-mode', type=str, choices=['uniform', 'surface', 'both'], default='both', help='Sampling mode')
     parser.add_argument('--gpu', action='store_true', help='Use GPU (always on in this build)')
     args = parser.parse_args(argv)
-    if args.bilateral_solver:
-        print('--bilateral-solver is not available in this build yet.')
-        sys.exit(1)
-
     d = Path(args.data)
     if args.num_samples == 0.0:
         args.sampling_mode = 'annotated'

@@ -11,6 +11,10 @@ its environment are provided here, none of them part of the algorithm:
   * the DINO model -- fetched from the network by the reference (infer.py:42-43); the oracle's restatement
     (oracle/dino_vit.py) with seeded synthetic weights stands in, driven through the reference's own
     ``compute_qkv`` harness (hook on blocks[-1].attn.qkv, K slicing, permutes, pooling, fp16 sum)
+  * bilateral_solver3d.py is broken at the reference's HEAD in this environment: it uses
+    ``F.`` without importing it and passes ``tol=`` to SciPy's cg, which SciPy >= 1.14 calls ``rtol``.  Both names are
+    bound in that module's namespace before it is called (``F`` = torch.nn.functional, ``cg`` = a wrapper mapping tol
+    to rtol); nothing else is touched
 Only inputs and expected outputs are stored -- no reference source.
 """
 import contextlib
@@ -29,7 +33,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = '/root/reference'
 sys.path.insert(0, ROOT)
 
-from oracle import dino_vit, feature_volume as ofv, similarity as osim, synthetic as osyn   # noqa: E402
+from oracle import bilateral as obil, dino_vit, feature_volume as ofv, similarity as osim, synthetic as osyn   # noqa: E402
 import vit_tf_amd as vt   # noqa: E402  (weights recipe only; no GPU involved)
 
 TINY_ARCH = (128, 3, 2, 8)      # embed_dim, depth, heads, patch -- head dim 64 like every DINO ViT
@@ -63,6 +67,10 @@ def load_reference():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+    from scipy.sparse.linalg import cg as scipy_cg
+    bs_globals = ref_ntf.apply_bilateral_solver3d.__globals__
+    bs_globals['F'] = torch.nn.functional
+    bs_globals['cg'] = lambda A, b, x0=None, M=None, maxiter=None, tol=1e-5: scipy_cg(A, b, x0=x0, M=M, maxiter=maxiter, rtol=tol)
     return ref_infer, ref_ntf, ref_syn
 
 
@@ -185,6 +193,49 @@ def similarity_case(ref_ntf):
     return rec
 
 
+def bilateral_case(ref_ntf):
+    """(1) apply_bilateral_solver3d on a 20x18x22 target / grey reference; (2) compute_similarities(...,
+    bilateral_solver=True) end to end on an 8^3 x 64 feature volume under a 24x16x20 volume."""
+    g = torch.Generator().manual_seed(21)
+    shape = (20, 18, 22)
+    zz, yy, xx = torch.meshgrid(*[torch.linspace(-1, 1, n) for n in shape], indexing='ij')
+    blob = torch.exp(-4 * ((zz - 0.2) ** 2 + yy ** 2 + (xx + 0.1) ** 2))
+    ref = (255 * (0.15 + 0.7 * (blob > 0.35).float() + 0.1 * torch.rand(shape, generator=g))).clamp(0, 255).to(torch.uint8)
+    target = (blob + 0.3 * torch.randn(shape, generator=g)).clamp(0, 1)
+    out = quiet(ref_ntf.apply_bilateral_solver3d, target[None], ref.expand(3, -1, -1, -1),
+                grid_params={'sigma_spatial': 7, 'sigma_chroma': 5, 'sigma_luma': 5})
+    rec = {'solver_target': target.numpy(), 'solver_ref': ref.numpy(), 'solver_out': out.numpy()}
+    mine = obil.solve(target, ref)
+    err = float((mine - out).abs().max())
+    print(f'  oracle vs reference bilateral solve: max abs diff {err:.3e} (output range {float(out.min()):.3f}..{float(out.max()):.3f})')
+    assert err < 1e-6
+    conf_ref = ref_ntf.apply_bilateral_solver3d.__globals__['filter_sobel_separated'](ref[None, None].float() / 255.0)[0, 0]
+    assert torch.equal(obil.sobel_confidence(ref), conf_ref.max() - conf_ref)
+
+    # end to end through the reference's compute_similarities
+    g = torch.Generator().manual_seed(22)
+    feat = torch.nn.functional.normalize(torch.randn((64, 8, 8, 8), generator=g), dim=0)
+    feat = (feat + 0.9 * feat[:, 2:3, 3:4, 4:5]).half().float()
+    feat = torch.nn.functional.normalize(feat, dim=0).half().float()
+    vshape = (24, 16, 20)
+    zz, yy, xx = torch.meshgrid(*[torch.linspace(-1, 1, n) for n in vshape], indexing='ij')
+    volume = (torch.exp(-3 * (zz ** 2 + yy ** 2 + xx ** 2)) * 900 - 400 + 20 * torch.randn(vshape, generator=g)).float()
+    ann = {'ntf1': torch.tensor([[7, 6, 10], [8, 7, 11]]), 'ntf2': torch.tensor([[12, 3, 1], [2, 13, 14], [8, 8, 8]])}
+    refs = quiet(ref_ntf.compute_similarities, volume.numpy(), feat, {k: v.clone() for k, v in ann.items()}, True)
+    rec.update({'e2e_feat': feat.numpy(), 'e2e_volume': volume.numpy()})
+    sims = osim.class_maps_fp32(tuple(vshape), feat, ann)
+    for k, v in ann.items():
+        rec[f'e2e_ann_{k}'] = v.numpy()
+        rec[f'e2e_sim_{k}'] = refs[k].numpy()
+        refined = obil.refine_similarity(sims[k], volume, tuple(d // 2 for d in vshape))
+        q, _ = osim.quantize_u8(refined)
+        d = (q.int() - refs[k].int()).abs()
+        d = torch.minimum(d, 256 - d)
+        print(f'  oracle vs reference bilateral e2e {k}: differing voxels {int((d > 0).sum())} / {d.numel()} (max {int(d.max())})')
+        assert int(d.max()) <= 1 and int((d > 0).sum()) <= 2, k
+    return rec
+
+
 def ref_ntf_thresholds():
     return [0.486, 0.264, 0.236, 0.68, 0.291]      # predict_ntf.py:208 (a local of its __main__, restated)
 
@@ -220,6 +271,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'sampling.npz'), **sampling_case(ref_infer))
     print('compute_similarities + labels')
     np.savez_compressed(os.path.join(HERE, 'similarity.npz'), **similarity_case(ref_ntf))
+    print('bilateral solver (bilateral_solver3d + compute_similarities(bilateral_solver=True))')
+    np.savez_compressed(os.path.join(HERE, 'bilateral.npz'), **bilateral_case(ref_ntf))
     print('create_synthetic_volumes --size 16')
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:

@@ -412,3 +412,61 @@ def test_cosine_similarity_option(gpu):
         d = torch.minimum(d, 256 - d)
         assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, k
         assert not torch.equal(got[k], raw[k])                   # and it is not the un-normalised map
+
+
+# ---------------------------------------------------------------- bilateral solver
+def _u8_close(a, b, max_frac=0.01):
+    d = (a.int() - b.int()).abs()
+    d = torch.minimum(d, 256 - d)
+    return int(d.max()) <= 1 and float((d > 0).float().mean()) <= max_frac
+
+
+def test_bilateral_e2e_golden(gpu, golden_dir):
+    """compute_similarities(..., bilateral_solver=True) against the reference's own output (fp64 CG on the device vs
+    SciPy: the maps may differ by one quantisation step on isolated voxels)."""
+    g = load_golden(golden_dir, 'bilateral.npz')
+    ann = {k: torch.from_numpy(g[f'e2e_ann_{k}']) for k in ('ntf1', 'ntf2')}
+    got = vt.compute_similarities(g['e2e_volume'], torch.from_numpy(g['e2e_feat']), ann, bilateral_solver=True)
+    for k in ann:
+        ref = torch.from_numpy(g[f'e2e_sim_{k}'])
+        assert got[k].shape == ref.shape and got[k].dtype == torch.uint8
+        assert _u8_close(got[k], ref), k
+
+
+@pytest.mark.parametrize('shape,sim_shape', [((40, 36, 44), (20, 18, 22)), ((30, 30, 30), (30, 30, 30)), ((17, 50, 23), (31, 25, 40))])
+def test_bilateral_refine_vs_oracle(gpu, shape, sim_shape):
+    """refine_similarity (resizes, uint8 reference, crop, Sobel confidence, grid, bistochastisation, PCG, slice) against
+    the CPU restatement at sizes with several spatial bins per axis, fp32 output compared directly."""
+    from oracle import bilateral as obil
+    gq = gen(sum(shape))
+    zz, yy, xx = torch.meshgrid(*[torch.linspace(-1, 1, n) for n in shape], indexing='ij')
+    blob = torch.exp(-3 * ((zz - 0.1) ** 2 + (yy + 0.2) ** 2 + xx ** 2))
+    volume = (blob * 800 - 300 + 15 * torch.randn(shape, generator=gq)).float()
+    n = tuple(max(4, s // 3) for s in shape)
+    sim = torch.nn.functional.interpolate(blob[None, None], n, mode='trilinear')[0, 0]
+    sim = (sim + 0.2 * torch.rand(n, generator=gq)).clamp(0, 1.2).float().contiguous()
+    info = {}
+    got = vt.bilateral.refine_similarity(sim.to(gpu), volume.to(gpu), sim_shape, info=info).cpu()
+    ref = obil.refine_similarity(sim, volume, sim_shape)
+    assert info['vertices'] > 8 and info['voxels'] > 0
+    err = (got - ref).abs()
+    # fp32 rounding of the trilinear resize can move a voxel across a uint8 / luma-bin edge (another vertex): rare
+    assert float((err > 1e-4).float().mean()) < 0.01, float(err.max())
+    assert float(err.median()) < 1e-6
+    assert _u8_close(vt.bilateral.quantize_u8(got.to(gpu)).cpu(), osim.quantize_u8(ref)[0])
+
+
+def test_bilateral_nothing_above_threshold(gpu):
+    sim = torch.full((8, 8, 8), 0.05)
+    vol = torch.rand((16, 16, 16), generator=gen(1))
+    info = {}
+    got = vt.bilateral.refine_similarity(sim.to(gpu), vol.to(gpu), (8, 8, 8), info=info).cpu()
+    assert info['vertices'] == 0 and torch.equal(got, sim)
+
+
+def test_quantize_wrap_u8(gpu):
+    sim = torch.randn(5000, generator=gen(2)).abs() * 0.3
+    sim[7] = sim.max() * 0.999          # lands on 256.x -> wraps to 0/1 like the x86 cast
+    sim[11] = -0.01                     # the solver may undershoot
+    got = vt.bilateral.quantize_u8(sim.to(gpu)).cpu()
+    assert torch.equal(got, osim.quantize_u8(sim)[0])

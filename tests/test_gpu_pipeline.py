@@ -211,6 +211,12 @@ def test_entry_points_end_to_end(gpu, tmp_path):
     assert {'mIoU', 'predict_time', 'fit_time', 'confusion_matrix'} <= set(metrics)
     r = run('predict_ntf.py', '--data', str(d), '--num-samples', '16', '--sampling-mode', 'uniform')
     assert r.returncode == 0 and 'Already inferred' in r.stdout
+    # the bilateral-solver post-process (predict_ntf.py:73-96) through the same entry point
+    r = run('predict_ntf.py', '--data', str(d), '--num-samples', '16', '--sampling-mode', 'uniform', '--bilateral-solver')
+    assert r.returncode == 0, r.stderr + r.stdout
+    pred_bls = np.load(d / 'ntf_pred16.0uniformbls.npy')
+    assert pred_bls.dtype == np.uint8 and pred_bls.shape == (16, 16, 16)
+    assert {'mIoU', 'confusion_matrix'} <= set(json.load(open(d / 'ntf_metrics16.0uniformbls.json')))
 
 
 def test_two_ranks_share_one_gpu_rehearsal(gpu, tmp_path):

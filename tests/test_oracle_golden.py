@@ -97,3 +97,38 @@ def test_pool_windows_are_adaptive_rule():
     assert torch.allclose(ref, mine)
     assert ofv.pool_windows(10, 4) == [(0, 3), (2, 5), (5, 8), (7, 10)]
     assert [vt.extract.window_bounds(i, 10, 4) for i in range(4)] == ofv.pool_windows(10, 4)
+
+
+def test_bilateral_solver_matches_reference_golden(golden_dir):
+    """oracle/bilateral.py against outputs of the reference's bilateral_solver3d / compute_similarities(...,
+    bilateral_solver=True) (tests/golden/make_golden.py: bilateral_case)."""
+    from oracle import bilateral as obil
+    g = load_golden(golden_dir, 'bilateral.npz')
+    out = obil.solve(torch.from_numpy(g['solver_target']), torch.from_numpy(g['solver_ref']))
+    assert float((out - torch.from_numpy(g['solver_out'])).abs().max()) < 1e-6
+    feat, vol = torch.from_numpy(g['e2e_feat']), torch.from_numpy(g['e2e_volume'])
+    ann = {k: torch.from_numpy(g[f'e2e_ann_{k}']) for k in ('ntf1', 'ntf2')}
+    got = osim.similarity_maps(tuple(vol.shape), feat, ann, volume=vol)
+    for k in ann:
+        assert torch.equal(got[k], torch.from_numpy(g[f'e2e_sim_{k}'])), k
+
+
+def test_bilateral_grid_structure():
+    """Vertex order = sorted hash order of the reference (lexicographic luma, z, y, x); splat / slice are adjoint;
+    the blur operator is symmetric."""
+    from oracle import bilateral as obil
+    gen = torch.Generator().manual_seed(3)
+    ref = (torch.rand((9, 15, 11), generator=gen) * 255).to(torch.uint8)
+    grid = obil.Grid(ref.numpy(), 7, 5, 5)
+    lut, _, _ = obil.yuv_bins_of_grey(5, 5)
+    w, h, d = ref.shape
+    iz, iy, ix = np.meshgrid(np.arange(w), np.arange(h), np.arange(d), indexing='ij')
+    coords = np.stack([ix // 7, iy // 7, iz // 7, lut[ref.numpy()]], -1).reshape(-1, 4)
+    hashes = coords.astype(np.float64) @ (255.0 ** np.arange(4))
+    uniq, inv = np.unique(hashes, return_inverse=True)
+    assert grid.nvertices == len(uniq) and np.array_equal(grid.vertex_of_voxel, inv)
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(grid.npixels), rng.standard_normal(grid.nvertices)
+    assert abs(np.dot(grid.splat(x), y) - np.dot(x, grid.slice(y))) < 1e-9
+    y2 = rng.standard_normal(grid.nvertices)
+    assert abs(np.dot(grid.blur(y), y2) - np.dot(y, grid.blur(y2))) < 1e-9

@@ -40,6 +40,12 @@ class VittfError(RuntimeError):
     pass
 
 
+class BilateralParams(C.Structure):
+    _fields_ = [('sigma_spatial', C.c_double), ('lam', C.c_double), ('a_diag_min', C.c_double), ('cg_tol', C.c_double),
+                ('cg_maxiter', C.c_int32), ('bistochastize_iters', C.c_int32), ('pad', C.c_int32),
+                ('crop_threshold', C.c_float)]
+
+
 _vp, _i32, _i64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
 _P = C.POINTER
 
@@ -68,6 +74,11 @@ SIGNATURES = {
     'vittf_similarity_workspace_bytes': (_sz, [_i32, _i64]),
     'vittf_similarity': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _P(_i32), _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp,
                                    _sz, _vp]),
+    'vittf_similarity_maps_f32': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _P(_i32), _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'vittf_bilateral_workspace_bytes': (_sz, [_i32, _i32, _i32, C.c_double, _i32]),
+    'vittf_bilateral_refine': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _P(_i32), _i32,
+                                         _P(BilateralParams), _vp, _P(_i32), _vp, _sz, _vp]),
+    'vittf_quantize_wrap_u8': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     'vittf_assign_labels': (C.c_int, [_vp, _i32, _i64, _P(_i32), _vp, _vp]),
 }
 

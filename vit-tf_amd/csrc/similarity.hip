@@ -278,24 +278,15 @@ extern "C" size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox
   return align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4) + (size_t)classes * (size_t)nvox * 4;
 }
 
-extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
-                                const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
-                                const float* voxel_norm, int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws,
-                                size_t ws_bytes, void* stream) {
-  if (!feat || !qf || !class_start_host || !out || !ws) return VITTF_ERR_INVALID_ARG;
-  if (f <= 0 || f > 4096 || n0 <= 0 || n1 <= 0 || n2 <= 0 || classes <= 0 || o0 <= 0 || o1 <= 0 || o2 <= 0)
-    return VITTF_ERR_INVALID_ARG;
-  const int64_t nvox = (int64_t)n0 * n1 * n2;
-  if (ws_bytes < vittf_similarity_workspace_bytes(classes, nvox)) return VITTF_ERR_WORKSPACE;
+namespace {
+// argument checks + the chunk walk shared by the two entry points: fp32 class maps [classes][nvox] into `sim`
+int accumulate_class_maps(const uint16_t* feat, int32_t f, int64_t nvox, const float* qf, const int32_t* class_start_host,
+                          int32_t classes, int32_t big_a_mean, const float* voxel_norm, float* sim, unsigned* maxbits,
+                          float* qf_t, hipStream_t st) {
   if (class_start_host[0] != 0) return VITTF_ERR_INVALID_ARG;
   for (int c = 0; c < classes; ++c)
     if (class_start_host[c + 1] <= class_start_host[c]) return VITTF_ERR_INVALID_ARG;  // empty class: caller drops it
   if (((uintptr_t)feat & 3) != 0) return VITTF_ERR_INVALID_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  char* wsb = (char*)ws;
-  unsigned* maxbits = (unsigned*)wsb;
-  float* qf_t = (float*)(wsb + align256((size_t)classes * 4));
-  float* sim = (float*)(wsb + align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4));
   if (hipMemsetAsync(maxbits, 0, (size_t)classes * 4, st) != hipSuccess) return VITTF_ERR_LAUNCH;
 
   const int total_a = class_start_host[classes];
@@ -332,12 +323,46 @@ extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int
       hipLaunchKernelGGL((sim_accumulate<false>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, sim, maxbits);
     a0 += n;
   }
+  return VITTF_OK;
+}
+}  // namespace
+
+extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
+                                const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
+                                const float* voxel_norm, int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws,
+                                size_t ws_bytes, void* stream) {
+  if (!feat || !qf || !class_start_host || !out || !ws) return VITTF_ERR_INVALID_ARG;
+  if (f <= 0 || f > 4096 || n0 <= 0 || n1 <= 0 || n2 <= 0 || classes <= 0 || o0 <= 0 || o1 <= 0 || o2 <= 0)
+    return VITTF_ERR_INVALID_ARG;
+  const int64_t nvox = (int64_t)n0 * n1 * n2;
+  if (ws_bytes < vittf_similarity_workspace_bytes(classes, nvox)) return VITTF_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* wsb = (char*)ws;
+  unsigned* maxbits = (unsigned*)wsb;
+  float* qf_t = (float*)(wsb + align256((size_t)classes * 4));
+  float* sim = (float*)(wsb + align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4));
+  const int rc = accumulate_class_maps(feat, f, nvox, qf, class_start_host, classes, big_a_mean, voxel_norm, sim, maxbits,
+                                       qf_t, st);
+  if (rc != VITTF_OK) return rc;
   const int64_t total_out = (int64_t)classes * o0 * o1 * o2;
   int64_t qblocks = (total_out + 255) / 256;
   if (qblocks > 8192) qblocks = 8192;
   hipLaunchKernelGGL(sim_quantize, dim3((unsigned)qblocks), dim3(256), 0, st, sim, maxbits, classes, n0, n1, n2, o0, o1,
                      o2, out);
   return vittf_check_launch();
+}
+
+extern "C" int vittf_similarity_maps_f32(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
+                                         const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
+                                         const float* voxel_norm, float* maps_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!feat || !qf || !class_start_host || !maps_out || !ws) return VITTF_ERR_INVALID_ARG;
+  if (f <= 0 || f > 4096 || n0 <= 0 || n1 <= 0 || n2 <= 0 || classes <= 0) return VITTF_ERR_INVALID_ARG;
+  const int64_t nvox = (int64_t)n0 * n1 * n2;
+  if (ws_bytes < align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4)) return VITTF_ERR_WORKSPACE;
+  char* wsb = (char*)ws;
+  const int rc = accumulate_class_maps(feat, f, nvox, qf, class_start_host, classes, big_a_mean, voxel_norm, maps_out,
+                                       (unsigned*)wsb, (float*)(wsb + align256((size_t)classes * 4)), (hipStream_t)stream);
+  return rc != VITTF_OK ? rc : vittf_check_launch();
 }
 
 extern "C" int vittf_assign_labels(const uint8_t* sims, int32_t classes, int64_t n, const int32_t* thr_host,

@@ -59,14 +59,14 @@ def sample_features3d(feat_vol, rel_coords, mode='nearest'):
 
 
 def compute_similarities(volume, features, annotations, bilateral_solver=False, device=None, normalize=False):
-    """predict_ntf.py:24-101 (bilateral_solver=False).  volume: (W, H, D) array/tensor (only its shape is
-    used); features: (F, W', H', D'); annotations: {name: (n, 3) voxel coords}.
+    """predict_ntf.py:24-101.  volume: (W, H, D) array/tensor (only its shape is used unless bilateral_solver);
+    features: (F, W', H', D'); annotations: {name: (n, 3) voxel coords}.
+    bilateral_solver=True: every class map is refined by the 3-D bilateral solver against the volume
+    (predict_ntf.py:73-96, bilateral.py) before quantisation, instead of the nearest resize.
     Returns {name: uint8 CPU tensor (W//2, H//2, D//2)}; None when there is nothing to query
     (predict_ntf.py:51-55).  Classes with zero annotations are skipped.
     normalize=True: cosine similarity -- the volume is L2-normalised per voxel first, as
     compare_feat_sampling.py:45 and tests/test_vishum.py:12 do (predict_ntf.py itself does not)."""
-    if bilateral_solver:
-        raise NotImplementedError('bilateral solver post-process is outside the round-1 hot path (SURVEY.md 8f-1)')
     if len(annotations) == 0:
         return None
     names = [k for k, v in annotations.items() if torch.as_tensor(v).shape[0] > 0]
@@ -96,6 +96,20 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
     nclass = len(names)
     ws_bytes = lib.vittf_similarity_workspace_bytes(nclass, n0 * n1 * n2)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    if bilateral_solver:
+        from . import bilateral
+        maps = torch.empty((nclass, n0, n1, n2), dtype=torch.float32, device=dev)
+        _lib.check(lib.vittf_similarity_maps_f32(_lib.ptr(feat), f, n0, n1, n2, _lib.ptr(qf),
+                                                 starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big, _lib.ptr(vnorm),
+                                                 _lib.ptr(maps), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                   'vittf_similarity_maps_f32')
+        vol = torch.as_tensor(np.asarray(volume, dtype=np.float32) if not isinstance(volume, torch.Tensor) else volume)
+        vol = vol.squeeze().to(device=dev, dtype=torch.float32).contiguous()
+        res = {}
+        for i, k in enumerate(names):
+            refined = bilateral.refine_similarity(maps[i], vol, sim_shape)
+            res[k] = bilateral.quantize_u8(refined).cpu()
+        return res
     out = torch.empty((nclass, *sim_shape), dtype=torch.uint8, device=dev)
     _lib.check(lib.vittf_similarity(_lib.ptr(feat), f, n0, n1, n2, _lib.ptr(qf),
                                     starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big, _lib.ptr(vnorm),
