@@ -73,6 +73,31 @@ def main():
             print(f'stock SDPA batch {batch} N {tokens}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s')
         except Exception as e:  # noqa: BLE001
             print('stock SDPA failed:', e)
+    if 'bilateral' in what:   # predict_ntf.py:73-96 for one class at the BASELINE configs[4] size (512^3 volume -> 256^3 maps)
+        import time
+        size = int(os.environ.get('BLS_SIZE', '512'))
+        vol, lab = vt.ct_like_volume(size, seed=0)
+        vol = vol.float().to(dev)
+        zz, yy, xx = torch.meshgrid(*[torch.linspace(-1, 1, 64)] * 3, indexing='ij')
+        sim = (torch.exp(-6 * ((zz - 0.1) ** 2 + yy ** 2 + (xx + 0.2) ** 2)) + 0.05 * torch.rand(64, 64, 64, generator=g)).to(dev)
+        shape = (size // 2,) * 3
+        info = {}
+        vt.bilateral.refine_similarity(sim, vol, shape, info=info)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out = vt.bilateral.refine_similarity(sim, vol, shape)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        print(f'bilateral refine {size}^3 volume -> {shape[0]}^3 map: {ms:.1f} ms  ({info["voxels"]} voxels in the crop box, {info["vertices"]} vertices)')
+        if os.environ.get('BLS_CPU', '0') == '1':
+            from oracle import bilateral as obil
+            t0 = time.perf_counter()
+            ref = obil.refine_similarity(sim.cpu(), vol.cpu(), shape)
+            cpu_s = time.perf_counter() - t0
+            err = (out.cpu() - ref).abs()
+            print(f'  CPU restatement (numpy fp64, 1 process): {cpu_s:.1f} s; GPU vs CPU: median |diff| {float(err.median()):.2e}, '
+                  f'voxels off by > 1e-3: {float((err > 1e-3).float().mean()):.2e}')
     if 'mlp' in what:
         hh = torch.randn(rows, d, generator=g).to(TDT[dt]).to(dev)
         w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(dev)
