@@ -235,12 +235,24 @@ int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, in
                      const int32_t* class_start_host, int32_t classes, int32_t big_a_mean, const float* voxel_norm,
                      int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws, size_t ws_bytes, void* stream);
 
-/* The fp32 per-class maps of vittf_similarity before quantisation and resizing: maps_out fp32 [classes][n0*n1*n2]
- * (predict_ntf.py:71-72; the input of the bilateral-solver branch :73-96).  ws: the first two regions of
- * vittf_similarity_workspace_bytes() suffice. */
-int vittf_similarity_maps_f32(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
-                              const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
-                              const float* voxel_norm, float* maps_out, void* ws, size_t ws_bytes, void* stream);
+/* fp32 per-group maps without quantisation or resizing: maps_out fp32 [classes][n0*n1*n2].
+ *   mode 0: predict_ntf.py:65-72 (the input of the bilateral-solver branch :73-96); mode 1: its A > 1024 variant (:62-63);
+ *   mode 2: the second similarity of resample_topk (infer.py:104-106): clamp(dot, 0, 1) ** exponent, mean over each group
+ *           of queries; feat may then be fp32 (feat_is_fp16 = 0), e.g. an already normalised volume.
+ * ws: the first two regions of vittf_similarity_workspace_bytes() suffice. */
+int vittf_similarity_maps_f32(const void* feat, int32_t feat_is_fp16, int32_t f, int32_t n0, int32_t n1, int32_t n2,
+                              const float* qf, const int32_t* class_start_host, int32_t classes, int32_t mode,
+                              float exponent, const float* voxel_norm, float* maps_out, void* ws, size_t ws_bytes,
+                              void* stream);
+
+/* Per map (nmaps maps of nvox fp32 values): the first k voxel indices, in index order, whose value is >= the k-th largest
+ * value of the map -- torch.topk(s.flatten(), K).values[-1]; (s >= that).nonzero()[:K]  (infer.py:95-96).
+ * idx_out int32 [nmaps][k] (device). */
+int vittf_topk_voxels(const float* maps, int32_t nmaps, int64_t nvox, int32_t k, int32_t* idx_out, void* stream);
+
+/* take_most_dissimilar's distance (infer.py:118-121): dist[i] = 1 - mean_j cos(x_i, x_j) (measure 0, F.cosine_similarity
+ * with eps 1e-8) or mean_j |x_i - x_j|_2 (measure 1, torch.cdist); x fp32 [n][f], dist fp32 [n]. */
+int vittf_mean_pairwise_distance(const float* x, int32_t n, int32_t f, int32_t measure, float* dist, void* stream);
 
 /* ---- 3-D bilateral solver post-process (bilateral_solver3d.py, predict_ntf.py:73-96) ---------- */
 typedef struct vittf_bilateral_params {

@@ -110,11 +110,13 @@ def sample_features3d(feat_vol, rel_coords, mode='nearest'):
 
 
 def resample_topk(feat_vol, sims, K=8, similarity_exponent=2.0, feature_sampling_mode='nearest'):
-    raise NotImplementedError('resample_topk is not on the round-1 hot path (never called in the reference; SURVEY.md 8f-2)')
+    """(:75-106) top-K voxels per (class, annotation) map -> re-sampled queries -> mean clamp(sim, 0, 1) ** exponent."""
+    return vt.similarity.resample_topk(feat_vol, sims, K, similarity_exponent, feature_sampling_mode)
 
 
 def take_most_dissimilar(features, num_prototypes=35, measure='cosine'):
-    raise NotImplementedError('take_most_dissimilar is not on the round-1 hot path (SURVEY.md 8f-2)')
+    """(:108-126) the num_prototypes rows with the largest mean cosine / euclidean distance to all rows."""
+    return vt.similarity.take_most_dissimilar(features, num_prototypes, measure)
 
 
 def _noop(x, **kwargs):

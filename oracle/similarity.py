@@ -107,6 +107,40 @@ def similarity_maps(volume_shape, features, annotations, normalize=False, volume
     return out
 
 
+def resample_topk(feat_vol, sims, K=8, similarity_exponent=2.0, mode='nearest'):
+    """infer.py:75-106.  feat_vol (M, F, W, H, D) fp32; sims (M, C, A, W, H, D).  Returns (M, C, A, W, H, D)."""
+    m, c, a = sims.shape[:3]
+    dims = sims.shape[-3:]
+    out = torch.empty((m, c, a, *dims), dtype=torch.float32)
+    ext = torch.tensor(list(dims), dtype=torch.float32)
+    for mi in range(m):
+        flat = feat_vol[mi].reshape(feat_vol.shape[1], -1).float()
+        for ci in range(c):
+            for ai in range(a):
+                s = sims[mi, ci, ai]
+                kth = torch.topk(s.flatten(), K).values[-1]
+                top = (s >= kth).nonzero()[:K]                                   # first K in index order
+                rel = (top.float() + 0.5) / ext * 2.0 - 1.0
+                qf = sample_features(feat_vol[mi].float(), rel, mode)             # (K, F)
+                out[mi, ci, ai] = ((qf @ flat).clamp(0, 1) ** similarity_exponent).mean(0).reshape(dims)
+    return out
+
+
+def mean_pairwise_distance(features, measure='cosine'):
+    """infer.py:118-121: the per-row distance take_most_dissimilar ranks by."""
+    if measure == 'cosine':
+        return 1 - F.cosine_similarity(features[None], features[:, None], dim=-1).mean(0)
+    return torch.cdist(features[None], features[None])[0].mean(0)
+
+
+def take_most_dissimilar(features, num_prototypes=35, measure='cosine'):
+    """infer.py:108-126; the order of the returned rows is unspecified (topk(sorted=False)): compare as a set."""
+    if features.shape[0] <= num_prototypes:
+        return features
+    dist = mean_pairwise_distance(features, measure)
+    return features[torch.topk(dist, num_prototypes, largest=True, sorted=False).indices]
+
+
 def assign_labels(sims, thresholds=CT_ORG_THRESHOLDS):
     """predict_ntf.py:203-215: per-class threshold + running maximum -> uint8 labels.
 

@@ -236,6 +236,31 @@ def bilateral_case(ref_ntf):
     return rec
 
 
+def refinement_case(ref_infer):
+    """resample_topk and take_most_dissimilar (infer.py:75-126), outputs of the reference's own functions."""
+    g = torch.Generator().manual_seed(31)
+    feat = torch.nn.functional.normalize(torch.randn((1, 48, 6, 7, 5), generator=g), dim=1)
+    sims = torch.rand((1, 2, 3, 6, 7, 5), generator=g)
+    sims[0, 0, 1, 2, 3, 1] = sims[0, 0, 1, 4, 0, 2] = 0.9999                  # a tie inside the top K
+    rec = {'rt_feat': feat.numpy(), 'rt_sims': sims.numpy()}
+    for K, expo, mode in ((3, 2.0, 'nearest'), (8, 1.5, 'bilinear')):
+        ref = quiet(ref_infer.resample_topk, feat.clone(), sims.clone(), K, expo, mode)
+        rec[f'rt_out_K{K}'] = ref.numpy()
+        got = osim.resample_topk(feat, sims, K, expo, mode)
+        err = float((got - ref).abs().max())
+        print(f'  oracle vs reference resample_topk K={K}: max abs diff {err:.2e}')
+        assert err < 1e-6
+    x = torch.randn((60, 24), generator=g)
+    x[7] = x[3] * 2.0                                                            # cosine-identical rows
+    rec['md_x'] = x.numpy()
+    for measure in ('cosine', 'euclidean'):
+        ref = quiet(ref_infer.take_most_dissimilar, x.clone(), 9, measure)
+        rec[f'md_{measure}'] = ref.numpy()
+        mine = osim.take_most_dissimilar(x, 9, measure)
+        assert sorted(map(tuple, mine.tolist())) == sorted(map(tuple, ref.tolist())), measure
+    return rec
+
+
 def ref_ntf_thresholds():
     return [0.486, 0.264, 0.236, 0.68, 0.291]      # predict_ntf.py:208 (a local of its __main__, restated)
 
@@ -273,6 +298,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'similarity.npz'), **similarity_case(ref_ntf))
     print('bilateral solver (bilateral_solver3d + compute_similarities(bilateral_solver=True))')
     np.savez_compressed(os.path.join(HERE, 'bilateral.npz'), **bilateral_case(ref_ntf))
+    print('resample_topk / take_most_dissimilar')
+    np.savez_compressed(os.path.join(HERE, 'refinement.npz'), **refinement_case(ref_infer))
     print('create_synthetic_volumes --size 16')
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:

@@ -470,3 +470,53 @@ def test_quantize_wrap_u8(gpu):
     sim[11] = -0.01                     # the solver may undershoot
     got = vt.bilateral.quantize_u8(sim.to(gpu)).cpu()
     assert torch.equal(got, osim.quantize_u8(sim)[0])
+
+
+# ---------------------------------------------------------------- resample_topk / take_most_dissimilar
+def test_topk_voxels(gpu):
+    lib = _lib.load()
+    g = gen(40)
+    maps = torch.randn(5, 3000, generator=g)
+    maps[1, 10] = maps[1, 2000] = maps[1].max() + 1.0            # a tie at the top
+    maps[2] = 0.5                                                # all equal: the first K indices
+    maps[3, 77] = float('inf'); maps[3, 5] = -float('inf')
+    md = maps.to(gpu)
+    for k in (1, 4, 9):
+        idx = torch.empty((5, k), dtype=torch.int32, device=gpu)
+        _lib.check(lib.vittf_topk_voxels(_lib.ptr(md), 5, 3000, k, _lib.ptr(idx), _lib.stream_ptr()))
+        for i in range(5):
+            kth = torch.topk(maps[i], k).values[-1]
+            want = (maps[i] >= kth).nonzero()[:k, 0]
+            assert torch.equal(idx[i].cpu().long(), want), (i, k)
+
+
+def test_resample_topk_golden(gpu, golden_dir):
+    g = load_golden(golden_dir, 'refinement.npz')
+    feat, sims = torch.from_numpy(g['rt_feat']), torch.from_numpy(g['rt_sims'])
+    import infer as drop_in
+    for K, expo, mode in ((3, 2.0, 'nearest'), (8, 1.5, 'bilinear')):
+        got = drop_in.resample_topk(feat, sims, K, expo, mode).cpu()
+        ref = torch.from_numpy(g[f'rt_out_K{K}'])
+        assert got.shape == ref.shape and got.dtype == torch.float32
+        assert float((got - ref).abs().max()) < 2e-5
+    half = drop_in.resample_topk(feat.half(), sims[0], 3, 2.0, 'nearest').cpu()       # fp16 volume, 5-D sims
+    assert half.dtype == torch.float16 and half.shape == ref.shape
+    assert float((half.float() - osim.resample_topk(feat.half().float(), sims, 3, 2.0, 'nearest')).abs().max()) < 2e-3
+
+
+def test_take_most_dissimilar_golden(gpu, golden_dir):
+    g = load_golden(golden_dir, 'refinement.npz')
+    x = torch.from_numpy(g['md_x'])
+    import infer as drop_in
+    for measure in ('cosine', 'euclidean'):
+        got = drop_in.take_most_dissimilar(x, 9, measure)
+        assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, g[f'md_{measure}'].tolist())), measure
+        lib = _lib.load()
+        xd = x.to(gpu)
+        dist = torch.empty(x.shape[0], device=gpu)
+        _lib.check(lib.vittf_mean_pairwise_distance(_lib.ptr(xd), x.shape[0], x.shape[1], 0 if measure == 'cosine' else 1,
+                                                    _lib.ptr(dist), _lib.stream_ptr()))
+        assert torch.allclose(dist.cpu(), osim.mean_pairwise_distance(x, measure), atol=2e-6, rtol=1e-5)
+    assert drop_in.take_most_dissimilar(x[:5], 9) is x[:5] or torch.equal(drop_in.take_most_dissimilar(x[:5], 9), x[:5])
+    with pytest.raises(ValueError):
+        drop_in.take_most_dissimilar(x, 9, 'manhattan')

@@ -132,3 +132,17 @@ def test_bilateral_grid_structure():
     assert abs(np.dot(grid.splat(x), y) - np.dot(x, grid.slice(y))) < 1e-9
     y2 = rng.standard_normal(grid.nvertices)
     assert abs(np.dot(grid.blur(y), y2) - np.dot(y, grid.blur(y2))) < 1e-9
+
+
+def test_refinement_helpers_match_reference_golden(golden_dir):
+    """resample_topk / take_most_dissimilar restatements against outputs of the reference's own functions."""
+    g = load_golden(golden_dir, 'refinement.npz')
+    feat, sims = torch.from_numpy(g['rt_feat']), torch.from_numpy(g['rt_sims'])
+    for K, expo, mode in ((3, 2.0, 'nearest'), (8, 1.5, 'bilinear')):
+        got = osim.resample_topk(feat, sims, K, expo, mode)
+        assert float((got - torch.from_numpy(g[f'rt_out_K{K}'])).abs().max()) < 1e-6
+    x = torch.from_numpy(g['md_x'])
+    for measure in ('cosine', 'euclidean'):
+        got = osim.take_most_dissimilar(x, 9, measure)
+        assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, g[f'md_{measure}'].tolist()))
+    assert osim.take_most_dissimilar(x[:5], 9) is not None and osim.take_most_dissimilar(x[:5], 9).shape[0] == 5

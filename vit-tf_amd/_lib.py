@@ -74,7 +74,10 @@ SIGNATURES = {
     'vittf_similarity_workspace_bytes': (_sz, [_i32, _i64]),
     'vittf_similarity': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _P(_i32), _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp,
                                    _sz, _vp]),
-    'vittf_similarity_maps_f32': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _P(_i32), _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'vittf_similarity_maps_f32': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _P(_i32), _i32, _i32, C.c_float, _vp, _vp,
+                                            _vp, _sz, _vp]),
+    'vittf_topk_voxels': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp]),
+    'vittf_mean_pairwise_distance': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     'vittf_bilateral_workspace_bytes': (_sz, [_i32, _i32, _i32, C.c_double, _i32]),
     'vittf_bilateral_refine': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _P(_i32), _i32,
                                          _P(BilateralParams), _vp, _P(_i32), _vp, _sz, _vp]),

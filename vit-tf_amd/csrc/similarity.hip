@@ -123,10 +123,18 @@ __device__ __forceinline__ float thresh_pow(float s) {
   return s >= 0.25f ? s * s * sqrtf(s) : 0.f;
 }
 
-template <bool BIG>
-__global__ __launch_bounds__(256) void sim_accumulate(const unsigned short* __restrict__ feat, int f, int64_t nvox,
+// ACT 0: where(s >= 0.25, s, 0) ** 2.5 (predict_ntf.py:71);  ACT 1: clamp(s, 0, 1) ** expo (infer.py:104, resample_topk)
+template <int ACT>
+__device__ __forceinline__ float activate(float s, float expo) {
+  if constexpr (ACT == 0) return thresh_pow(s);
+  const float c = fminf(fmaxf(s, 0.f), 1.f);
+  return c > 0.f ? __builtin_amdgcn_exp2f(expo * __builtin_amdgcn_logf(c)) : 0.f;   // v_log_f32 is log2
+}
+
+template <bool BIG, int ACT, bool HALF>
+__global__ __launch_bounds__(256) void sim_accumulate(const void* __restrict__ feat_v, int f, int64_t nvox,
                                                       const float* __restrict__ qf_t, SimChunk ch,
-                                                      const float* __restrict__ vnorm, float* __restrict__ sim,
+                                                      const float* __restrict__ vnorm, float expo, float* __restrict__ sim,
                                                       unsigned* __restrict__ maxbits) {
   const int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VPT;
   float acc[ACH][VPT];
@@ -140,13 +148,19 @@ __global__ __launch_bounds__(256) void sim_accumulate(const unsigned short* __re
 #pragma unroll 8
     for (int ff = 0; ff < f; ++ff) {
       float x[VPT];
-      const unsigned short* p = feat + (int64_t)ff * nvox + v0;
-      if (vec) {
-        const unsigned raw = *reinterpret_cast<const unsigned*>(p);
-        x[0] = f16bits_to_f32((unsigned short)(raw & 0xffff)); x[1] = f16bits_to_f32((unsigned short)(raw >> 16));
-      } else {
+      if constexpr (HALF) {
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(feat_v) + (int64_t)ff * nvox + v0;
+        if (vec) {
+          const unsigned raw = *reinterpret_cast<const unsigned*>(p);
+          x[0] = f16bits_to_f32((unsigned short)(raw & 0xffff)); x[1] = f16bits_to_f32((unsigned short)(raw >> 16));
+        } else {
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) x[j] = (v0 + j < nvox) ? f16bits_to_f32(p[j]) : 0.f;
+          for (int j = 0; j < VPT; ++j) x[j] = (v0 + j < nvox) ? f16bits_to_f32(p[j]) : 0.f;
+        }
+      } else {
+        const float* p = reinterpret_cast<const float*>(feat_v) + (int64_t)ff * nvox + v0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) x[j] = (v0 + j < nvox) ? p[j] : 0.f;
       }
       const float* q = qf_t + ff * ACH;   // wave-uniform -> scalar loads
 #pragma unroll
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(256) void sim_accumulate(const unsigned short* __re
       for (int a = 0; a < ACH; ++a)
         if (a < ch.n_ann && ch.cls[a] == c) {
 #pragma unroll
-          for (int j = 0; j < VPT; ++j) cs[j] += BIG ? acc[a][j] : thresh_pow(acc[a][j]);
+          for (int j = 0; j < VPT; ++j) cs[j] += BIG ? acc[a][j] : activate<ACT>(acc[a][j], expo);
         }
       float* dst = sim + (int64_t)(ch.c0 + c) * nvox + v0;
 #pragma unroll
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(256) void sim_accumulate(const unsigned short* __re
           if (!ch.first[c]) t += dst[j];
           if (ch.last[c]) {
             t = t / ch.count[c];                // mean = sum / count (predict_ntf.py:72 / :63), true division
-            if (BIG) t = thresh_pow(t);
+            if (BIG) t = activate<ACT>(t, expo);
             blockmax[c] = fmaxf(blockmax[c], t);
           }
           dst[j] = t;
@@ -280,9 +294,12 @@ extern "C" size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox
 
 namespace {
 // argument checks + the chunk walk shared by the two entry points: fp32 class maps [classes][nvox] into `sim`
-int accumulate_class_maps(const uint16_t* feat, int32_t f, int64_t nvox, const float* qf, const int32_t* class_start_host,
-                          int32_t classes, int32_t big_a_mean, const float* voxel_norm, float* sim, unsigned* maxbits,
-                          float* qf_t, hipStream_t st) {
+// mode 0: predict_ntf (threshold / power per annotation, class mean); 1: its single-class A > 1024 variant (mean of the
+// dots first); 2: resample_topk (clamp(0, 1) ** expo per query, group mean)
+int accumulate_class_maps(const void* feat, bool half, int32_t f, int64_t nvox, const float* qf,
+                          const int32_t* class_start_host, int32_t classes, int32_t mode, float expo,
+                          const float* voxel_norm, float* sim, unsigned* maxbits, float* qf_t, hipStream_t st) {
+  if (mode < 0 || mode > 2 || (!half && mode != 2)) return VITTF_ERR_INVALID_ARG;
   if (class_start_host[0] != 0) return VITTF_ERR_INVALID_ARG;
   for (int c = 0; c < classes; ++c)
     if (class_start_host[c + 1] <= class_start_host[c]) return VITTF_ERR_INVALID_ARG;  // empty class: caller drops it
@@ -317,10 +334,14 @@ int accumulate_class_maps(const uint16_t* feat, int32_t f, int64_t nvox, const f
       ch.count[i] = (float)(class_start_host[cc + 1] - class_start_host[cc]);
     }
     hipLaunchKernelGGL(transpose_queries, dim3((f * ACH + 255) / 256), dim3(256), 0, st, qf, f, a0, n, qf_t);
-    if (big_a_mean)
-      hipLaunchKernelGGL((sim_accumulate<true>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, sim, maxbits);
+    if (mode == 1)
+      hipLaunchKernelGGL((sim_accumulate<true, 0, true>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, expo, sim, maxbits);
+    else if (mode == 0)
+      hipLaunchKernelGGL((sim_accumulate<false, 0, true>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, expo, sim, maxbits);
+    else if (half)
+      hipLaunchKernelGGL((sim_accumulate<false, 1, true>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, expo, sim, maxbits);
     else
-      hipLaunchKernelGGL((sim_accumulate<false>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, sim, maxbits);
+      hipLaunchKernelGGL((sim_accumulate<false, 1, false>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, expo, sim, maxbits);
     a0 += n;
   }
   return VITTF_OK;
@@ -341,8 +362,8 @@ extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int
   unsigned* maxbits = (unsigned*)wsb;
   float* qf_t = (float*)(wsb + align256((size_t)classes * 4));
   float* sim = (float*)(wsb + align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4));
-  const int rc = accumulate_class_maps(feat, f, nvox, qf, class_start_host, classes, big_a_mean, voxel_norm, sim, maxbits,
-                                       qf_t, st);
+  const int rc = accumulate_class_maps(feat, true, f, nvox, qf, class_start_host, classes, big_a_mean ? 1 : 0, 0.f,
+                                       voxel_norm, sim, maxbits, qf_t, st);
   if (rc != VITTF_OK) return rc;
   const int64_t total_out = (int64_t)classes * o0 * o1 * o2;
   int64_t qblocks = (total_out + 255) / 256;
@@ -352,16 +373,18 @@ extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int
   return vittf_check_launch();
 }
 
-extern "C" int vittf_similarity_maps_f32(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
-                                         const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
-                                         const float* voxel_norm, float* maps_out, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int vittf_similarity_maps_f32(const void* feat, int32_t feat_is_fp16, int32_t f, int32_t n0, int32_t n1,
+                                         int32_t n2, const float* qf, const int32_t* class_start_host, int32_t classes,
+                                         int32_t mode, float exponent, const float* voxel_norm, float* maps_out, void* ws,
+                                         size_t ws_bytes, void* stream) {
   if (!feat || !qf || !class_start_host || !maps_out || !ws) return VITTF_ERR_INVALID_ARG;
   if (f <= 0 || f > 4096 || n0 <= 0 || n1 <= 0 || n2 <= 0 || classes <= 0) return VITTF_ERR_INVALID_ARG;
   const int64_t nvox = (int64_t)n0 * n1 * n2;
   if (ws_bytes < align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4)) return VITTF_ERR_WORKSPACE;
   char* wsb = (char*)ws;
-  const int rc = accumulate_class_maps(feat, f, nvox, qf, class_start_host, classes, big_a_mean, voxel_norm, maps_out,
-                                       (unsigned*)wsb, (float*)(wsb + align256((size_t)classes * 4)), (hipStream_t)stream);
+  const int rc = accumulate_class_maps(feat, feat_is_fp16 != 0, f, nvox, qf, class_start_host, classes, mode, exponent,
+                                       voxel_norm, maps_out, (unsigned*)wsb, (float*)(wsb + align256((size_t)classes * 4)),
+                                       (hipStream_t)stream);
   return rc != VITTF_OK ? rc : vittf_check_launch();
 }
 

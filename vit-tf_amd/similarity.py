@@ -99,9 +99,9 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
     if bilateral_solver:
         from . import bilateral
         maps = torch.empty((nclass, n0, n1, n2), dtype=torch.float32, device=dev)
-        _lib.check(lib.vittf_similarity_maps_f32(_lib.ptr(feat), f, n0, n1, n2, _lib.ptr(qf),
-                                                 starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big, _lib.ptr(vnorm),
-                                                 _lib.ptr(maps), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+        _lib.check(lib.vittf_similarity_maps_f32(_lib.ptr(feat), 1, f, n0, n1, n2, _lib.ptr(qf),
+                                                 starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big, 0.0,
+                                                 _lib.ptr(vnorm), _lib.ptr(maps), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
                    'vittf_similarity_maps_f32')
         vol = torch.as_tensor(np.asarray(volume, dtype=np.float32) if not isinstance(volume, torch.Tensor) else volume)
         vol = vol.squeeze().to(device=dev, dtype=torch.float32).contiguous()
@@ -132,3 +132,68 @@ def assign_labels(similarities, thresholds=CT_ORG_THRESHOLDS, device=None):
     _lib.check(lib.vittf_assign_labels(_lib.ptr(sims), len(maps), n, thr, _lib.ptr(labels), _lib.stream_ptr()),
                'vittf_assign_labels')
     return labels.cpu().numpy()
+
+
+def resample_topk(feat_vol, sims, K=8, similarity_exponent=2.0, feature_sampling_mode='nearest'):
+    """infer.py:75-106: re-sample the feature volume at the K most similar voxels of every (class, annotation) map and
+    average the K new similarity maps clamp(feat . q, 0, 1) ** exponent.
+    feat_vol ([M,] F, W, H, D) fp16 / fp32 (normalised, as the caller of the reference passes it); sims ([M,] C, A, W, H, D).
+    Returns ([M,] C, A, W, H, D) in feat_vol's dtype, on the GPU."""
+    lib = _lib.require_device()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    fv = torch.as_tensor(feat_vol)
+    sv = torch.as_tensor(sims)
+    if fv.ndim == 4:
+        fv = fv[None]
+    if sv.ndim == 5:
+        sv = sv[None]
+    m, c, a = sv.shape[:3]
+    dims = tuple(int(d) for d in sv.shape[-3:])
+    if tuple(fv.shape[-3:]) != dims or fv.shape[0] != m:
+        raise ValueError(f'feature volume {tuple(fv.shape)} and similarity volume {tuple(sv.shape)} do not match')
+    nvox = dims[0] * dims[1] * dims[2]
+    f = fv.shape[1]
+    is_half = fv.dtype == torch.float16
+    fv = fv.to(dev, torch.float16 if is_half else torch.float32).contiguous()
+    sv = sv.to(dev, torch.float32).contiguous()
+    idx = torch.empty((m * c * a, K), dtype=torch.int32, device=dev)
+    _lib.check(lib.vittf_topk_voxels(_lib.ptr(sv), m * c * a, nvox, K, _lib.ptr(idx), _lib.stream_ptr()), 'vittf_topk_voxels')
+    flat = idx.to(torch.int64)
+    coords = torch.stack((flat // (dims[1] * dims[2]), (flat // dims[2]) % dims[1], flat % dims[2]), -1).float()
+    rel = ((coords + 0.5) / torch.tensor(dims, dtype=torch.float32, device=dev) * 2.0 - 1.0).reshape(m, c * a * K, 3)
+    out = torch.empty((m, c * a, nvox), dtype=torch.float32, device=dev)
+    groups = c * a
+    starts = (np.arange(groups + 1) * K).astype(np.int32)
+    ws_bytes = lib.vittf_similarity_workspace_bytes(groups, 1)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    for i in range(m):
+        qf = torch.empty((groups * K, f), dtype=torch.float32, device=dev)
+        reli = rel[i].contiguous()
+        _lib.check(lib.vittf_sample_features(_lib.ptr(fv[i]), int(is_half), f, dims[0], dims[1], dims[2], _lib.ptr(reli),
+                                             groups * K, _lib.SAMPLE_MODES[feature_sampling_mode], None, _lib.ptr(qf),
+                                             _lib.stream_ptr()), 'vittf_sample_features')
+        _lib.check(lib.vittf_similarity_maps_f32(_lib.ptr(fv[i]), int(is_half), f, dims[0], dims[1], dims[2], _lib.ptr(qf),
+                                                 starts.ctypes.data_as(C.POINTER(C.c_int32)), groups, 2,
+                                                 float(similarity_exponent), None, _lib.ptr(out[i]), _lib.ptr(ws), ws_bytes,
+                                                 _lib.stream_ptr()), 'vittf_similarity_maps_f32')
+    out = out.reshape(m, c, a, *dims).to(torch.float16 if is_half else torch.float32)
+    return out          # always with the M dimension, like the reference (it unsqueezes 5-D sims in place)
+
+
+def take_most_dissimilar(features, num_prototypes=35, measure='cosine'):
+    """infer.py:108-126: the num_prototypes rows of features (N, F) with the largest mean distance to all rows."""
+    feats = torch.as_tensor(features)
+    if feats.shape[0] <= num_prototypes:
+        return feats
+    if measure not in ('cosine', 'euclidean'):
+        raise ValueError(f'Unknown measure: {measure}')
+    lib = _lib.require_device()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    x = feats.to(dev, torch.float32).contiguous()
+    n, f = x.shape
+    dist = torch.empty((1, n), dtype=torch.float32, device=dev)
+    _lib.check(lib.vittf_mean_pairwise_distance(_lib.ptr(x), n, f, 0 if measure == 'cosine' else 1, _lib.ptr(dist),
+                                                _lib.stream_ptr()), 'vittf_mean_pairwise_distance')
+    sel = torch.empty((1, num_prototypes), dtype=torch.int32, device=dev)
+    _lib.check(lib.vittf_topk_voxels(_lib.ptr(dist), 1, n, num_prototypes, _lib.ptr(sel), _lib.stream_ptr()), 'vittf_topk_voxels')
+    return feats[sel[0].to(torch.int64).to(feats.device)]
