@@ -220,7 +220,7 @@ int vittf_sample_features(const void* feat, int32_t feat_is_fp16, int32_t f, int
  * compare_feat_sampling.py:45 / tests/test_vishum.py:12 -- without materialising a normalised copy. */
 int vittf_voxel_norm(const uint16_t* feat, int32_t f, int64_t nvox, float* out, void* stream);
 
-size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox);
+size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox, int32_t annotations);
 
 /* Fused similarity: for every voxel v and class c with annotations [class_start[c], class_start[c+1]):
  *     dot[a] = sum_f feat[f][v] * qf[a][f]                       (einsum predict_ntf.py:65)
@@ -239,7 +239,7 @@ int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, in
  *   mode 0: predict_ntf.py:65-72 (the input of the bilateral-solver branch :73-96); mode 1: its A > 1024 variant (:62-63);
  *   mode 2: the second similarity of resample_topk (infer.py:104-106): clamp(dot, 0, 1) ** exponent, mean over each group
  *           of queries; feat may then be fp32 (feat_is_fp16 = 0), e.g. an already normalised volume.
- * ws: the first two regions of vittf_similarity_workspace_bytes() suffice. */
+ * ws: vittf_similarity_workspace_bytes(classes, 0, annotations) bytes (no fp32 map region needed). */
 int vittf_similarity_maps_f32(const void* feat, int32_t feat_is_fp16, int32_t f, int32_t n0, int32_t n1, int32_t n2,
                               const float* qf, const int32_t* class_start_host, int32_t classes, int32_t mode,
                               float exponent, const float* voxel_norm, float* maps_out, void* ws, size_t ws_bytes,

@@ -520,3 +520,25 @@ def test_take_most_dissimilar_golden(gpu, golden_dir):
     assert drop_in.take_most_dissimilar(x[:5], 9) is x[:5] or torch.equal(drop_in.take_most_dissimilar(x[:5], 9), x[:5])
     with pytest.raises(ValueError):
         drop_in.take_most_dissimilar(x, 9, 'manhattan')
+
+
+@pytest.mark.parametrize('normalize', [False, True])
+def test_similarity_many_annotations_mfma_path(gpu, normalize):
+    """A >= 64 and F = 384 take the matrix-core path (sim_mfma.hip: volume read once, fp16 hi + lo queries, classes
+    padded to 32-query chunks): against the oracle, incl. a 1-annotation class and a voxel count that is not a multiple
+    of the 256-voxel workgroup tile."""
+    g = gen(77 + int(normalize))
+    feat = torch.nn.functional.normalize(torch.randn(384, 20, 18, 22, generator=g), dim=0)
+    feat = (feat + 0.7 * feat[:, 5:6, 6:7, 7:8]).half()
+    if not normalize:
+        feat = torch.nn.functional.normalize(feat.float(), dim=0).half()
+    shape = (40, 36, 44)
+    ann = {'a': torch.randint(0, 36, (100, 3), generator=g), 'b': torch.tensor([[10, 12, 14]]),
+           'c': torch.randint(0, 36, (300, 3), generator=g)}
+    got = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann, normalize=normalize)
+    ref = osim.similarity_maps(shape, feat.float(), ann, normalize=normalize)
+    for k in ann:
+        assert int(ref[k].max()) > 20
+        d = (got[k].int() - ref[k].int()).abs()
+        d = torch.minimum(d, 256 - d)
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, (k, int(d.max()), float((d > 0).float().mean()))

@@ -122,6 +122,11 @@ def main():
             vol = np.zeros((256, 256, 256), np.float32)
             ms = timeit(lambda: vt.compute_similarities(vol, feat, ann), reps=5, warm=2)
             print(f'similarity 64^3x384, A={na}: {ms:.3f} ms end-to-end  ({feat.numel() * 2 / ms / 1e6:.0f} GB/s of feature bytes, {262144 * na / ms / 1e3:.0f} Mvoxel-sim/s)')
+        # BASELINE configs[4]: 1024 annotations for each of 5 classes (VITTF_SIM_MFMA=0 keeps the VALU kernel)
+        ann = {f'c{i}': torch.randint(0, 256, (1024, 3), generator=g) for i in range(5)}
+        ms = timeit(lambda: vt.compute_similarities(vol, feat, ann), reps=3, warm=1)
+        print(f'similarity 64^3x384, A=5x1024 (VITTF_SIM_MFMA={os.environ.get("VITTF_SIM_MFMA", "1")}): {ms:.2f} ms end-to-end  '
+              f'({262144 * 5120 / ms / 1e3:.0f} Mvoxel-sim/s, {2 * 262144 * 5120 * 384 / ms / 1e9:.1f} TFLOP/s of dot products)')
 
 
 if __name__ == '__main__':

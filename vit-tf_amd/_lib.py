@@ -71,7 +71,7 @@ SIGNATURES = {
     'vittf_assemble_sum': (C.c_int, [_vp, _vp, _vp, _i32, _P(_i32), _i32, _i32, _i32, _i32, _vp, _vp]),
     'vittf_sample_features': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     'vittf_voxel_norm': (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
-    'vittf_similarity_workspace_bytes': (_sz, [_i32, _i64]),
+    'vittf_similarity_workspace_bytes': (_sz, [_i32, _i64, _i32]),
     'vittf_similarity': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _P(_i32), _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp,
                                    _sz, _vp]),
     'vittf_similarity_maps_f32': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _P(_i32), _i32, _i32, C.c_float, _vp, _vp,

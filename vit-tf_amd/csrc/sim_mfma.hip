@@ -1,0 +1,166 @@
+// Per-class similarity maps for MANY annotations on the matrix cores (F = 384).
+//
+// Same arithmetic as sim_accumulate (similarity.hip; predict_ntf.py:65, 71-72): for every voxel and class,
+// mean over the class's annotations of where(q . x >= 0.25, q . x, 0) ** 2.5.  The VALU kernel re-reads the whole
+// feature volume for every 16 annotations (A = 5 x 1024, BASELINE configs[4]: 320 passes over 201 MB); here the
+// volume is read ONCE:
+//   * workgroup = 8 waves = 256 voxels; a wave keeps the 384 features of its 32 voxels as 24 MFMA B-operands
+//     (96 VGPRs) for the whole kernel -- the volume is the stationary operand, the queries stream;
+//   * the queries are prepared once per call (sim_mfma_prep) as fp16 hi + lo halves (q = hi + lo to 2^-22; the
+//     volume is fp16 exactly, accumulation is fp32), padded per class to a multiple of 32 with zero rows (a zero
+//     query contributes where(0 >= 0.25) = 0) and stored in the LDS image order, so a 32-query chunk (48 KB) is
+//     a linear LDS-DMA copy into a 2-deep ring;
+//   * per chunk and wave 48 x v_mfma_f32_32x32x16_f16 (rows = queries, columns = voxels), then the activation and
+//     the in-lane sum over the 16 query rows a lane holds; one barrier per chunk.
+#include "vittf_common.h"
+
+#include <vector>
+
+namespace {
+
+constexpr int SM_F = 384, SM_KS = 24, SM_THREADS = 512, SM_VOX = 256;
+constexpr int SM_PART = 6 * 4096;       // one [32 queries][384] fp16 image: six [32][64] sub-images
+constexpr int SM_CHUNK = 2 * SM_PART;   // hi + lo: 48 KB
+
+// padded query p (class-major, each class padded to a multiple of 32) <- source row src_row[p] (-1: zero row)
+__global__ __launch_bounds__(256) void sim_mfma_prep(const float* __restrict__ qf, const int* __restrict__ src_row,
+                                                     int padded, char* __restrict__ img) {
+  const int e = blockIdx.x * 256 + threadIdx.x;          // one 16-byte chunk of one padded row
+  if (e >= padded * 48) return;
+  const int p = e / 48, c = e - 48 * p;
+  const int src = src_row[p];
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float q0 = 0.f, q1 = 0.f;
+    if (src >= 0) { q0 = qf[(int64_t)src * SM_F + 8 * c + 2 * j]; q1 = qf[(int64_t)src * SM_F + 8 * c + 2 * j + 1]; }
+    const unsigned short h0 = f32_to_f16bits(q0), h1 = f32_to_f16bits(q1);
+    const unsigned short l0 = f32_to_f16bits(q0 - f16bits_to_f32(h0)), l1 = f32_to_f16bits(q1 - f16bits_to_f32(h1));
+    hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+    lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+  char* dst = img + (int64_t)(p >> 5) * SM_CHUNK + (c >> 3) * 4096 + tile_off(p & 31, c & 7);
+  *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  *reinterpret_cast<uint4*>(dst + SM_PART) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+__device__ __forceinline__ float sm_thresh_pow(float s) { return s >= 0.25f ? s * s * sqrtf(s) : 0.f; }
+
+__global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned short* __restrict__ feat, int64_t nvox,
+                                                              const char* __restrict__ qimg,
+                                                              const int* __restrict__ chunk_start,
+                                                              const float* __restrict__ counts, int classes,
+                                                              const float* __restrict__ vnorm, float* __restrict__ sim,
+                                                              unsigned* __restrict__ maxbits) {
+  __shared__ __attribute__((aligned(16))) char ring[2 * SM_CHUNK];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int64_t v = (int64_t)blockIdx.x * SM_VOX + wave * 32 + l31;
+  const bool valid = v < nvox;
+
+  // the wave's 32 voxels x 384 features as B operands: xf[s] = features 16 s + 8 h .. + 7 of voxel v
+  s16x8_t xf[SM_KS];
+#pragma unroll
+  for (int s = 0; s < SM_KS; ++s) {
+    s16x8_t t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = valid ? (short)feat[(int64_t)(16 * s + 8 * h + j) * nvox + v] : (short)0;
+    xf[s] = t;
+  }
+  const float nv = (vnorm && valid) ? vnorm[v] : 1.f;
+
+  const int total = chunk_start[classes];
+  const i32x4_t rsrc = lds_dma_rsrc(qimg, (unsigned)((int64_t)total * SM_CHUNK < 0x7fffffff ? (int64_t)total * SM_CHUNK : 0x7fffffff));
+  const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(ring);
+  const int voff = lane * 16;
+  // chunk g -> ring[g & 1]: 48 pieces of 1 KB, 6 per wave
+#define SM_STAGE(G)                                                                                     \
+  {                                                                                                     \
+    const unsigned dst_ = ring_lds + ((G) & 1) * SM_CHUNK + wave * 6144;                                \
+    const int src_ = (G) * SM_CHUNK + wave * 6144;                                                      \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) lds_dma16(rsrc, dst_ + i * 1024, voff, src_ + i * 1024); \
+  }
+  const int aoff0 = tile_off(l31, h);
+  if (total > 0) SM_STAGE(0)
+  int g = 0;
+  for (int c = 0; c < classes; ++c) {
+    float csum = 0.f;
+    const int g_end = chunk_start[c + 1];
+    for (; g < g_end; ++g) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // chunk g landed; ring[(g + 1) & 1] is free
+      if (g + 1 < total) SM_STAGE(g + 1)
+      const char* buf = ring + (g & 1) * SM_CHUNK;
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < SM_KS; ++s) {
+        const int off = (s >> 2) * 4096 + (aoff0 ^ (32 * (s & 3)));
+        const s16x8_t qh = *reinterpret_cast<const s16x8_t*>(buf + off);
+        const s16x8_t ql = *reinterpret_cast<const s16x8_t*>(buf + SM_PART + off);
+        acc = mfma32<VITTF_FP16>(qh, xf[s], acc);
+        acc = mfma32<VITTF_FP16>(ql, xf[s], acc);
+      }
+      float part0 = 0.f, part1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        part0 += sm_thresh_pow(vnorm ? acc[r] / nv : acc[r]);
+        part1 += sm_thresh_pow(vnorm ? acc[r + 1] / nv : acc[r + 1]);
+      }
+      csum += part0 + part1;
+    }
+    // the two lane halves hold the other 16 query rows of every chunk
+    const unsigned cb = __float_as_uint(csum);
+    const auto sw = __builtin_amdgcn_permlane32_swap(cb, cb, false, false);
+    const float mean = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) / counts[c];
+    if (valid && h == 0) sim[(int64_t)c * nvox + v] = mean;
+    float m = valid ? mean : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0 && m > 0.f) atomicMax(maxbits + c, __float_as_uint(m));
+  }
+#undef SM_STAGE
+}
+
+}  // namespace
+
+size_t vittf_sim_mfma_workspace_bytes(int32_t classes, int32_t annotations) {
+  // worst case: every class padded by 31 rows; + the row map, chunk table and class counts
+  const size_t chunks = ((size_t)annotations + 31 * (size_t)classes + 31) / 32;
+  return chunks * SM_CHUNK + ((chunks * 32 * 4 + 255) & ~(size_t)255) + (((size_t)classes + 1) * 8 + 255 & ~(size_t)255) + 256;
+}
+
+// fp32 class maps [classes][nvox] + per-class maxima; returns 1 when this path does not apply
+int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, const float* qf, const int32_t* class_start_host,
+                        int32_t classes, const float* voxel_norm, float* sim, unsigned* maxbits, void* ws, size_t ws_bytes,
+                        hipStream_t st) {
+  const int total_a = class_start_host[classes];
+  if (f != SM_F || total_a < 64) return 1;
+  if (!ws || ws_bytes < vittf_sim_mfma_workspace_bytes(classes, total_a)) return 1;
+  std::vector<int> src_row, chunk_start(classes + 1, 0);
+  std::vector<float> counts(classes);
+  for (int c = 0; c < classes; ++c) {
+    const int n = class_start_host[c + 1] - class_start_host[c];
+    counts[c] = (float)n;
+    for (int i = 0; i < ((n + 31) & ~31); ++i) src_row.push_back(i < n ? class_start_host[c] + i : -1);
+    chunk_start[c + 1] = (int)(src_row.size() / 32);
+  }
+  const int padded = (int)src_row.size();
+  const size_t chunks = (size_t)padded / 32;
+  char* w = (char*)ws;
+  char* img = w;
+  int* src_d = (int*)(w + chunks * SM_CHUNK);
+  int* chunk_d = (int*)((char*)src_d + (((size_t)padded * 4 + 255) & ~(size_t)255));
+  float* counts_d = (float*)(chunk_d + classes + 1);
+  if (hipMemcpyAsync(src_d, src_row.data(), (size_t)padded * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(chunk_d, chunk_start.data(), ((size_t)classes + 1) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(counts_d, counts.data(), (size_t)classes * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+    return VITTF_ERR_LAUNCH;
+  hipLaunchKernelGGL(sim_mfma_prep, dim3((padded * 48 + 255) / 256), dim3(256), 0, st, qf, src_d, padded, img);
+  const unsigned blocks = (unsigned)((nvox + SM_VOX - 1) / SM_VOX);
+  hipLaunchKernelGGL(sim_mfma_kernel, dim3(blocks), dim3(SM_THREADS), 0, st, feat, nvox, img, chunk_d, counts_d, classes,
+                     voxel_norm, sim, maxbits);
+  if (hipStreamSynchronize(st) != hipSuccess) return VITTF_ERR_LAUNCH;   // the host vectors above must outlive the copies
+  return vittf_check_launch();
+}

@@ -10,6 +10,8 @@
 // are wave-uniform (scalar loads of a transposed [F][16] copy); all arithmetic is fp32 like the reference CPU path.
 #include "vittf_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 // ---------------------------------------------------------------- query sampling (grid_sample 3-D)
@@ -286,10 +288,29 @@ extern "C" int vittf_voxel_norm(const uint16_t* feat, int32_t f, int64_t nvox, f
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox) {
-  if (classes <= 0 || nvox <= 0) return 0;
-  // [max bits per class | transposed query chunk (F <= 4096) | fp32 class maps]
-  return align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4) + (size_t)classes * (size_t)nvox * 4;
+size_t vittf_sim_mfma_workspace_bytes(int32_t classes, int32_t annotations);                      // sim_mfma.hip
+int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, const float* qf, const int32_t* class_start_host,
+                        int32_t classes, const float* voxel_norm, float* sim, unsigned* maxbits, void* ws, size_t ws_bytes,
+                        hipStream_t st);                                                         // 1 = not applicable
+
+namespace {
+struct SimWs { size_t maxbits, qf_t, mfma, mfma_bytes, maps, total; };
+SimWs sim_ws_layout(int32_t classes, int64_t nvox, int32_t annotations) {
+  // [max bits per class | transposed query chunk (F <= 4096) | padded fp16 query images (many annotations) | fp32 class maps]
+  SimWs L{};
+  L.maxbits = 0;
+  L.qf_t = align256((size_t)classes * 4);
+  L.mfma = L.qf_t + align256((size_t)4096 * ACH * 4);
+  L.mfma_bytes = annotations >= 64 ? align256(vittf_sim_mfma_workspace_bytes(classes, annotations)) : 0;
+  L.maps = L.mfma + L.mfma_bytes;
+  L.total = L.maps + (size_t)classes * (size_t)nvox * 4;
+  return L;
+}
+}  // namespace
+
+extern "C" size_t vittf_similarity_workspace_bytes(int32_t classes, int64_t nvox, int32_t annotations) {
+  if (classes <= 0 || nvox < 0 || annotations < 0) return 0;
+  return sim_ws_layout(classes, nvox, annotations).total;
 }
 
 namespace {
@@ -298,7 +319,8 @@ namespace {
 // dots first); 2: resample_topk (clamp(0, 1) ** expo per query, group mean)
 int accumulate_class_maps(const void* feat, bool half, int32_t f, int64_t nvox, const float* qf,
                           const int32_t* class_start_host, int32_t classes, int32_t mode, float expo,
-                          const float* voxel_norm, float* sim, unsigned* maxbits, float* qf_t, hipStream_t st) {
+                          const float* voxel_norm, float* sim, unsigned* maxbits, float* qf_t, void* mfma_ws,
+                          size_t mfma_ws_bytes, hipStream_t st) {
   if (mode < 0 || mode > 2 || (!half && mode != 2)) return VITTF_ERR_INVALID_ARG;
   if (class_start_host[0] != 0) return VITTF_ERR_INVALID_ARG;
   for (int c = 0; c < classes; ++c)
@@ -307,6 +329,14 @@ int accumulate_class_maps(const void* feat, bool half, int32_t f, int64_t nvox, 
   if (hipMemsetAsync(maxbits, 0, (size_t)classes * 4, st) != hipSuccess) return VITTF_ERR_LAUNCH;
 
   const int total_a = class_start_host[classes];
+  if (mode == 0 && half && mfma_ws_bytes) {   // many annotations, F = 384: the volume is read once (sim_mfma.hip)
+    static const bool use_mfma = [] { const char* e = getenv("VITTF_SIM_MFMA"); return !e || atoi(e) != 0; }();
+    if (use_mfma) {
+      const int rc = vittf_sim_mfma_maps((const unsigned short*)feat, f, nvox, qf, class_start_host, classes, voxel_norm, sim,
+                                         maxbits, mfma_ws, mfma_ws_bytes, st);
+      if (rc != 1) return rc;
+    }
+  }
   const int64_t threads = (nvox + VPT - 1) / VPT;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
   // walk the annotation list in chunks of ACH; a chunk may span several (at most MAXC) classes
@@ -356,14 +386,16 @@ extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int
   if (f <= 0 || f > 4096 || n0 <= 0 || n1 <= 0 || n2 <= 0 || classes <= 0 || o0 <= 0 || o1 <= 0 || o2 <= 0)
     return VITTF_ERR_INVALID_ARG;
   const int64_t nvox = (int64_t)n0 * n1 * n2;
-  if (ws_bytes < vittf_similarity_workspace_bytes(classes, nvox)) return VITTF_ERR_WORKSPACE;
+  if (class_start_host[classes] < 0) return VITTF_ERR_INVALID_ARG;
+  const SimWs L = sim_ws_layout(classes, nvox, class_start_host[classes]);
+  if (ws_bytes < L.total) return VITTF_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   char* wsb = (char*)ws;
   unsigned* maxbits = (unsigned*)wsb;
-  float* qf_t = (float*)(wsb + align256((size_t)classes * 4));
-  float* sim = (float*)(wsb + align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4));
+  float* qf_t = (float*)(wsb + L.qf_t);
+  float* sim = (float*)(wsb + L.maps);
   const int rc = accumulate_class_maps(feat, true, f, nvox, qf, class_start_host, classes, big_a_mean ? 1 : 0, 0.f,
-                                       voxel_norm, sim, maxbits, qf_t, st);
+                                       voxel_norm, sim, maxbits, qf_t, wsb + L.mfma, L.mfma_bytes, st);
   if (rc != VITTF_OK) return rc;
   const int64_t total_out = (int64_t)classes * o0 * o1 * o2;
   int64_t qblocks = (total_out + 255) / 256;
@@ -380,11 +412,13 @@ extern "C" int vittf_similarity_maps_f32(const void* feat, int32_t feat_is_fp16,
   if (!feat || !qf || !class_start_host || !maps_out || !ws) return VITTF_ERR_INVALID_ARG;
   if (f <= 0 || f > 4096 || n0 <= 0 || n1 <= 0 || n2 <= 0 || classes <= 0) return VITTF_ERR_INVALID_ARG;
   const int64_t nvox = (int64_t)n0 * n1 * n2;
-  if (ws_bytes < align256((size_t)classes * 4) + align256((size_t)4096 * ACH * 4)) return VITTF_ERR_WORKSPACE;
+  if (class_start_host[classes] < 0) return VITTF_ERR_INVALID_ARG;
+  const SimWs L = sim_ws_layout(classes, 0, class_start_host[classes]);
+  if (ws_bytes < L.total) return VITTF_ERR_WORKSPACE;
   char* wsb = (char*)ws;
   const int rc = accumulate_class_maps(feat, feat_is_fp16 != 0, f, nvox, qf, class_start_host, classes, mode, exponent,
-                                       voxel_norm, maps_out, (unsigned*)wsb, (float*)(wsb + align256((size_t)classes * 4)),
-                                       (hipStream_t)stream);
+                                       voxel_norm, maps_out, (unsigned*)wsb, (float*)(wsb + L.qf_t), wsb + L.mfma,
+                                       L.mfma_bytes, (hipStream_t)stream);
   return rc != VITTF_OK ? rc : vittf_check_launch();
 }
 

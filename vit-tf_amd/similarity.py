@@ -94,7 +94,7 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
     starts = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
     big = int(len(annotations) == 1 and counts[0] > 1024)      # predict_ntf.py:62
     nclass = len(names)
-    ws_bytes = lib.vittf_similarity_workspace_bytes(nclass, n0 * n1 * n2)
+    ws_bytes = lib.vittf_similarity_workspace_bytes(nclass, n0 * n1 * n2, a_total)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     if bilateral_solver:
         from . import bilateral
@@ -164,7 +164,7 @@ def resample_topk(feat_vol, sims, K=8, similarity_exponent=2.0, feature_sampling
     out = torch.empty((m, c * a, nvox), dtype=torch.float32, device=dev)
     groups = c * a
     starts = (np.arange(groups + 1) * K).astype(np.int32)
-    ws_bytes = lib.vittf_similarity_workspace_bytes(groups, 1)
+    ws_bytes = lib.vittf_similarity_workspace_bytes(groups, 0, groups * K)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     for i in range(m):
         qf = torch.empty((groups * K, f), dtype=torch.float32, device=dev)
