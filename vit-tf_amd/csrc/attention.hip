@@ -261,18 +261,31 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void attn_kernel(const unsigned s
   // staging and synchronising but skip the arithmetic (3 of 4 waves in 1 of 33 workgroups at N = 4097)
   const bool active = __builtin_amdgcn_readfirstlane(qt * QT + wave * 32) < tokens;
   int t = 0;
-  for (; t + 1 < nt; ++t) {      // every tile but the last: the DMA of tile t + 1 flies under the MFMAs of t
-    if (t & 1) {
-      ATTN_STAGE_TILE(t + 1, 0)
-      if (active) attn_tile<DT, 1, false, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c);
-    } else {
-      ATTN_STAGE_TILE(t + 1, 1)
-      if (active) attn_tile<DT, 0, false, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c);
+  if (!active) {   // a separate loop: with `if (active)` around the tile body hipcc keeps the 32 output accumulators in
+                   // two register sets and copies them at every loop head (32 v_mov per tile on the hot path)
+    for (; t + 1 < nt; ++t) {
+      if (t & 1) ATTN_STAGE_TILE(t + 1, 0) else ATTN_STAGE_TILE(t + 1, 1)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed ...
-    __syncthreads();                                    // ... and everybody's have, and everybody is done reading
+    return;
   }
-  if (!active) return;          // no barrier after this point
+  // every tile but the last: the DMA of tile t + 1 flies under the MFMAs of t.  Two tiles per trip, straight-line (an
+  // `if (t & 1)` diamond makes hipcc give the two ring-buffer variants different accumulator registers + copies)
+#define ATTN_STEP(BUFC, BUFN)                                                                                          \
+  {                                                                                                                    \
+    ATTN_STAGE_TILE(t + 1, BUFN)                                                                                       \
+    attn_tile<DT, BUFC, false, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c); \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* this wave's DMA pieces have landed ... */                    \
+    __syncthreads();                                    /* ... and everybody's have, and everybody is done reading */  \
+    ++t;                                                                                                               \
+  }
+  while (t + 2 < nt) {
+    ATTN_STEP(0, 1)
+    ATTN_STEP(1, 0)
+  }
+  if (t + 1 < nt) ATTN_STEP(0, 1)
+#undef ATTN_STEP
   if (t & 1) attn_tile<DT, 1, true, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c);
   else       attn_tile<DT, 0, true, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c);
 
