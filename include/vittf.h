@@ -166,6 +166,13 @@ typedef enum vittf_epilogue {
 int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
                int32_t epilogue, int32_t tokens, int32_t dtype, void* stream);
 
+/* LayerNorm fused into the weight-stationary GEMM (K = 384 only): out = epilogue(LayerNorm(x; g, b, eps) . W^T + bias),
+ * x fp32 [rows][384] (the residual stream), epilogue VITTF_EPI_BIAS / _BIAS_GELU / _BIAS_QKV, 16-bit out [rows][n],
+ * n % 384 == 0.  Replaces norm1 + attn.qkv and norm2 + mlp.fc1 of a block without the 16-bit LayerNorm tensor ever
+ * reaching HBM.  Other shapes: VITTF_ERR_INVALID_ARG (use vittf_layernorm + vittf_gemm). */
+int vittf_ln_gemm(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const void* w, const float* bias,
+                  void* out, int64_t rows, int32_t n, int32_t k, int32_t epilogue, int32_t dtype, void* stream);
+
 /* Fused MLP of one block for D == 384:  x[rows][D] (fp32) += fc2(gelu_erf(fc1(h) + b1)) + b2 without ever writing the
  * [rows][4D] hidden activation.  h: h16 [rows][D] (LayerNorm2 output); w1: h16 [4D][D]; w2_perm: h16 [D][4D] in the
  * vittf_vit_weights.fc2_w_perm order.  Same result as vittf_gemm(BIAS_GELU) + vittf_gemm(BIAS_RESIDUAL) up to the

@@ -542,3 +542,38 @@ def test_similarity_many_annotations_mfma_path(gpu, normalize):
         d = (got[k].int() - ref[k].int()).abs()
         d = torch.minimum(d, 256 - d)
         assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, (k, int(d.max()), float((d > 0).float().mean()))
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows,n,epi', [(1, 384, 'bias'), (77, 1152, 'bias'), (4097, 1536, 'gelu'), (19205, 1152, 'bias')])
+def test_ln_gemm_fused(gpu, dt, rows, n, epi):
+    """LayerNorm inside the weight-stationary GEMM's loader against LayerNorm (fp64) -> rounding to the operand type ->
+    GEMM (fp64), and against the two separate kernels."""
+    lib = _lib.load()
+    g = gen(rows + n)
+    x = torch.randn(rows, 384, generator=g) * 2.0 + 0.3 * torch.randn(1, 384, generator=g)
+    lg, lb = 1.0 + 0.2 * torch.randn(384, generator=g), 0.1 * torch.randn(384, generator=g)
+    w = (torch.randn(n, 384, generator=g) / 384 ** 0.5).to(TDT[dt])
+    bias = 0.2 * torch.randn(n, generator=g)
+    code = _lib.EPI_BIAS if epi == 'bias' else _lib.EPI_BIAS_GELU
+    xd, gd, bd, wd, biasd = x.to(gpu), lg.to(gpu), lb.to(gpu), w.to(gpu), bias.to(gpu)
+    out = torch.full((rows + 2, n), 7.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_ln_gemm(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), 1e-6, _lib.ptr(wd), _lib.ptr(biasd), _lib.ptr(out),
+                                 rows, n, 384, code, _lib.DTYPES[dt], _lib.stream_ptr()))
+    got = out.float().cpu().double()
+    assert (got[rows:] == 7.0).all(), 'wrote past the last row'
+    h = F.layer_norm(x.double(), (384,), lg.double(), lb.double(), 1e-6).to(TDT[dt]).double()
+    ref = h @ w.double().t() + bias.double()
+    if epi == 'gelu':
+        ref = F.gelu(ref)
+    # a LayerNorm output on a rounding boundary may round the other way than in fp64: allow one operand ulp of slack
+    assert ((got[:rows] - ref).abs() <= EPS[dt] * ref.abs() * 1.01 + 3 * EPS[dt] + 1e-3).all()
+    assert rel_fro(got[:rows], ref) <= EPS[dt]
+    # the unfused pair of kernels
+    hd = torch.empty(rows, 384, dtype=TDT[dt], device=gpu)
+    out2 = torch.empty(rows, n, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_layernorm(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), _lib.ptr(hd), rows, 384, 1e-6, _lib.DTYPES[dt],
+                                   _lib.stream_ptr()))
+    _lib.check(lib.vittf_gemm(_lib.ptr(hd), _lib.ptr(wd), _lib.ptr(biasd), _lib.ptr(out2), rows, n, 384, code, 0,
+                              _lib.DTYPES[dt], _lib.stream_ptr()))
+    assert rel_fro(got[:rows], out2.float().cpu().double()) <= EPS[dt] / 2

@@ -119,11 +119,17 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   { ProfScope ps(VITTF_KERNEL_PATCH_EMBED, stream); rc = vittf_patch_embed(cfg, w, pos, view, slice0, batch, X, stream); }
   if (rc) return rc;
   const size_t esz = 2;
+  // ViT-S: LayerNorm is computed inside the qkv / fc1 GEMMs' activation loader (vittf_ln_gemm); VITTF_LN_FUSED=0 keeps
+  // the separate LayerNorm launches
+  static const bool ln_fused_env = [] { const char* e = getenv("VITTF_LN_FUSED"); return !e || atoi(e) != 0; }();
+  const bool ln_fused = ln_fused_env && d == 384 && !(w->fc2_w_perm);
   for (int l = 0; l < L; ++l) {
     const char* qkv_w = (const char*)w->qkv_w + (size_t)l * 3 * d * d * esz;
-    { ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
-      rc = vittf_layernorm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream); }
-    if (rc) return rc;
+    if (!ln_fused || l == L - 1) {
+      ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
+      rc = vittf_layernorm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
+      if (rc) return rc;
+    }
     if (l == L - 1) {
       // hooked tensor, one third only: rows [part*D, (part+1)*D) of qkv.weight / qkv.bias  (infer.py:189-201)
       ProfScope ps(VITTF_KERNEL_GEMM, stream);
@@ -135,8 +141,13 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
     // pipeline (176 VGPRs / 2 waves per SIMD against 128 / 4 for the online-maximum kernel)
     static const int pre = [] { const char* e = getenv("VITTF_ATTN_PRESCALED"); return e ? atoi(e) : 0; }();
     { ProfScope ps(VITTF_KERNEL_GEMM, stream);
-      rc = vittf_gemm(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, 0,
-                      dt, stream); }
+      if (ln_fused)
+        rc = vittf_ln_gemm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, cfg->ln_eps, qkv_w,
+                           w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, dt,
+                           stream);
+      else
+        rc = vittf_gemm(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d,
+                        pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, 0, dt, stream); }
     if (rc) return rc;
     { ProfScope ps(VITTF_KERNEL_ATTENTION, stream);
       rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, pre, stream); }
@@ -145,9 +156,11 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
       rc = vittf_gemm(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d, d,
                       VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
     if (rc) return rc;
-    { ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
-      rc = vittf_layernorm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream); }
-    if (rc) return rc;
+    if (!ln_fused) {
+      ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
+      rc = vittf_layernorm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
+      if (rc) return rc;
+    }
     if (d == 384 && w->fc2_w_perm) {
       ProfScope ps(VITTF_KERNEL_MLP, stream);
       rc = vittf_mlp_fused(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d,
@@ -156,8 +169,13 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
       if (rc) return rc;
     } else {
       { ProfScope ps(VITTF_KERNEL_GEMM, stream);
-        rc = vittf_gemm(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows,
-                        4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream); }
+        if (ln_fused)
+          rc = vittf_ln_gemm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, cfg->ln_eps,
+                             (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows, 4 * d,
+                             d, VITTF_EPI_BIAS_GELU, dt, stream);
+        else
+          rc = vittf_gemm(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows,
+                          4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream); }
       if (rc) return rc;
       { ProfScope ps(VITTF_KERNEL_GEMM, stream);
         rc = vittf_gemm(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,

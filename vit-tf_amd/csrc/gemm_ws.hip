@@ -59,10 +59,19 @@ __device__ __forceinline__ void ws_stage(const unsigned short* __restrict__ A, i
   }
 }
 
-template <int DT, int EPI>
+// LNF: the activations are LayerNorm(x) of an fp32 residual stream x[rows][384], computed here instead of by a separate
+// kernel: waves 0..3 fetch their 8 rows of the next tile as raw fp32 (12 KB each, linear LDS-DMA) and, after the
+// tile's stores have been handed to the storer waves, normalise them (8 lanes per row: mean, centred variance, affine;
+// the arithmetic of layernorm.hip) straight into the 16-bit operand image of the ring.
+template <int DT, int EPI, bool LNF>
 __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_ws_kernel(
-    const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
-    unsigned short* __restrict__ out, int64_t rows, int n, int n_mt, int total) {
+    const void* __restrict__ a_in, const unsigned short* __restrict__ W, const float* __restrict__ bias,
+    unsigned short* __restrict__ out, int64_t rows, int n, int n_mt, int total, const float* __restrict__ ln_g,
+    const float* __restrict__ ln_b, float ln_eps) {
+  const unsigned short* A = reinterpret_cast<const unsigned short*>(a_in);
+  const float* X = reinterpret_cast<const float*>(a_in);
+  __shared__ __attribute__((aligned(16))) char raw[LNF ? WBM * WK * 4 : 16];    // LNF: the next tile's fp32 rows
+  __shared__ __attribute__((aligned(16))) float gb_s[LNF ? 2 * WK : 4];         // LNF: gamma | beta
   // Separate LDS objects on purpose: hipcc orders ds_write / ds_read against outstanding LDS-DMA with vmcnt(0)
   // unless alias scopes (one per LDS variable) prove that they touch different memory.
   __shared__ __attribute__((aligned(16))) char smem[2 * WABYTES];    // the two activation tiles (LDS-DMA targets)
@@ -73,8 +82,11 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
   const int h = lane >> 5, l31 = lane & 31;
   const float* const bias_l = bias_s;
 
-  const int G = gridDim.x;
-  const int per = total / G, rem = total - per * G, bx = blockIdx.x;   // contiguous, balanced item ranges
+  // Work split: items = (panel, row tile), panel-major, contiguous balanced ranges.  (Giving the P panels of one range
+  // of row tiles to P workgroups of one XCD, so that an activation tile is fetched from HBM once, measured slower:
+  // qkv 0.129 -> 0.164 ms.)
+  const int G = gridDim.x, bx = blockIdx.x;
+  const int per = total / G, rem = total - per * G;
   const int it0 = bx * per + (bx < rem ? bx : rem), it1 = it0 + per + (bx < rem ? 1 : 0);
   if (it0 >= it1) return;
 
@@ -83,7 +95,8 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
   // Division of the vector-memory work (vmcnt retires in issue order, stores included, and a store takes
   // microseconds to retire under load): waves 0..5 issue all LDS-DMA and nothing else, so their counted wait at the
   // top of a tile covers DMA only; waves 6..11 issue all stores and never wait for them.
-  const bool loader = wave < 6;
+  const bool loader = wave < (LNF ? 4 : 6);
+  const bool storer = wave >= 6;
   int voff_a, voff_b;     // loader lanes: source byte offsets of chunk c and chunk c + 128 of a sub-image
   {
     int r, c;
@@ -92,10 +105,6 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
     tile_pos((tid & 127) + 128, r, c);
     voff_b = r * (WK * 2) + c * 16;
   }
-  const int ts = tid - 384;                          // storer thread index (waves 6..11)
-  const int r48 = ts / 48, c48 = ts - 48 * r48;     // staging tile -> global: row 8 i + r48, 16-byte chunk c48
-  const int st_lds = r48 * WCS + c48 * 16;           // (+ 8 i rows: immediates / scalar offsets)
-  const int st_glb = r48 * n * 2 + c48 * 16;
 
   // the finished-but-not-stored tile: fp32 values with bias (and q scale) applied, and where it goes
   float prev[16];
@@ -115,7 +124,12 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
   // ... and (after a barrier) the storer waves write the tile (M0, N0) as whole row segments; rows past the end
   // fall outside the descriptor and are dropped by the hardware
 #define WS_STORE(M0, N0)                                                                                        \
-  if (!loader) {                                                                                                \
+  if (storer) {                                                                                                 \
+    int ts_ = tid - 384;                              /* storer thread index (waves 6..11) */                   \
+    asm volatile("" : "+v"(ts_));                     /* (recomputed per tile: see WS_LN_TRANSFORM) */          \
+    const int r48 = ts_ / 48, c48 = ts_ - 48 * r48;  /* staging tile -> global: row 8 i + r48, 16-byte chunk c48 */ \
+    const int st_lds = r48 * WCS + c48 * 16;          /* (+ 8 i rows: immediates / scalar offsets) */           \
+    const int st_glb = r48 * n * 2 + c48 * 16;                                                                  \
     unsigned short* o16 = out + (M0) * n + (N0);                                                                \
     const int64_t left = ((rows - (M0)) * n - (N0)) * 2;                                                        \
     const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(                                                       \
@@ -127,7 +141,88 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
   }
 
   const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(smem);   // LDS byte address of the activation ring
-  if (loader) ws_stage(A, (int64_t)(it0 % n_mt) * WBM, rows, wave, voff_a, voff_b, ring_lds);
+  const unsigned raw_lds = (unsigned)(size_t)LDS_PTR(raw);
+  // LNF: raw rows of tile MT -> LDS (waves 0..3, 8 rows = 12 pieces of 1 KB each, rows past the end read as zeros) ...
+#define WS_STAGE_RAW(MT)                                                                                        \
+  {                                                                                                             \
+    const int64_t m0_ = (int64_t)(MT) * WBM;                                                                    \
+    const int64_t left_ = (rows - m0_) * (WK * 4);                                                              \
+    const i32x4_t rs_ = lds_dma_rsrc(X + m0_ * WK, (unsigned)(left_ < WBM * WK * 4 ? left_ : WBM * WK * 4));    \
+    _Pragma("unroll") for (int i = 0; i < 12; ++i)                                                              \
+      lds_dma16(rs_, raw_lds + wave * 12288 + i * 1024, lane * 16, wave * 12288 + i * 1024);                    \
+  }
+  // ... and (once landed) this wave's 8 rows -> LayerNorm -> 16-bit operand image BUF of the ring.  Lane = (row
+  // lane >> 3, segment lane & 7); a lane owns the 8-column chunks sg + 8 j, j = 0..5, i.e. chunk sg of sub-image j.
+#define WS_LN_TRANSFORM(BUF)                                                                                    \
+  {                                                                                                             \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+    int lane_ = lane;                                                                                           \
+    asm volatile("" : "+v"(lane_));   /* recompute the addresses here: as loop invariants they would be spilled */ \
+    const int r_ = 8 * wave + (lane_ >> 3), sg_ = lane_ & 7;                                                    \
+    const char* rr_ = raw + r_ * (WK * 4) + sg_ * 32;                                                           \
+    /* three passes over the lane's 48 values, each software-pipelined one chunk ahead (the LDS round trip would   */ \
+    /* otherwise be exposed 18 times); no deeper: 112 registers are taken by the weights and the pending tile      */ \
+    float4 ua_[2], ub_[2];                                                                                      \
+    float s_ = 0.f;                                                                                             \
+    ua_[0] = *reinterpret_cast<const float4*>(rr_); ub_[0] = *reinterpret_cast<const float4*>(rr_ + 16);        \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                             \
+      if (j + 1 < 6) { ua_[(j + 1) & 1] = *reinterpret_cast<const float4*>(rr_ + (j + 1) * 256);                \
+                       ub_[(j + 1) & 1] = *reinterpret_cast<const float4*>(rr_ + (j + 1) * 256 + 16); }         \
+      const float4 u0 = ua_[j & 1], u1 = ub_[j & 1];                                                            \
+      s_ += ((u0.x + u0.y) + (u0.z + u0.w)) + ((u1.x + u1.y) + (u1.z + u1.w));                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }                                                                                                           \
+    s_ += __shfl_xor(s_, 1); s_ += __shfl_xor(s_, 2); s_ += __shfl_xor(s_, 4);                                  \
+    const float mean_ = s_ / (float)WK;                                                                         \
+    float q_ = 0.f;                                                                                             \
+    ua_[0] = *reinterpret_cast<const float4*>(rr_); ub_[0] = *reinterpret_cast<const float4*>(rr_ + 16);        \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                             \
+      if (j + 1 < 6) { ua_[(j + 1) & 1] = *reinterpret_cast<const float4*>(rr_ + (j + 1) * 256);                \
+                       ub_[(j + 1) & 1] = *reinterpret_cast<const float4*>(rr_ + (j + 1) * 256 + 16); }         \
+      const float4 u0 = ua_[j & 1], u1 = ub_[j & 1];                                                            \
+      const float a0 = u0.x - mean_, a1 = u0.y - mean_, a2 = u0.z - mean_, a3 = u0.w - mean_;                   \
+      const float a4 = u1.x - mean_, a5 = u1.y - mean_, a6 = u1.z - mean_, a7 = u1.w - mean_;                   \
+      q_ += ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((a4 * a4 + a5 * a5) + (a6 * a6 + a7 * a7));          \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }                                                                                                           \
+    q_ += __shfl_xor(q_, 1); q_ += __shfl_xor(q_, 2); q_ += __shfl_xor(q_, 4);                                  \
+    const float rstd_ = 1.0f / sqrtf(q_ / (float)WK + ln_eps);                                                  \
+    char* dst_ = smem + (BUF) * WABYTES + tile_off(r_, sg_);                                                    \
+    const float* gp_ = gb_s + 8 * sg_;                                                                          \
+    float4 ga_[2], gc_[2], ba_[2], bc_[2];                                                                      \
+    ua_[0] = *reinterpret_cast<const float4*>(rr_); ub_[0] = *reinterpret_cast<const float4*>(rr_ + 16);        \
+    ga_[0] = *reinterpret_cast<const float4*>(gp_); gc_[0] = *reinterpret_cast<const float4*>(gp_ + 4);         \
+    ba_[0] = *reinterpret_cast<const float4*>(gp_ + WK); bc_[0] = *reinterpret_cast<const float4*>(gp_ + WK + 4); \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                             \
+      if (j + 1 < 6) {                                                                                          \
+        ua_[(j + 1) & 1] = *reinterpret_cast<const float4*>(rr_ + (j + 1) * 256);                               \
+        ub_[(j + 1) & 1] = *reinterpret_cast<const float4*>(rr_ + (j + 1) * 256 + 16);                          \
+        ga_[(j + 1) & 1] = *reinterpret_cast<const float4*>(gp_ + 64 * (j + 1));                                \
+        gc_[(j + 1) & 1] = *reinterpret_cast<const float4*>(gp_ + 64 * (j + 1) + 4);                            \
+        ba_[(j + 1) & 1] = *reinterpret_cast<const float4*>(gp_ + WK + 64 * (j + 1));                           \
+        bc_[(j + 1) & 1] = *reinterpret_cast<const float4*>(gp_ + WK + 64 * (j + 1) + 4);                       \
+      }                                                                                                         \
+      const float4 u0 = ua_[j & 1], u1 = ub_[j & 1], g0 = ga_[j & 1], g1 = gc_[j & 1], b0 = ba_[j & 1], b1 = bc_[j & 1]; \
+      uint4 pk_;                                                                                                \
+      pk_.x = pack2_h16<DT>((u0.x - mean_) * rstd_ * g0.x + b0.x, (u0.y - mean_) * rstd_ * g0.y + b0.y);        \
+      pk_.y = pack2_h16<DT>((u0.z - mean_) * rstd_ * g0.z + b0.z, (u0.w - mean_) * rstd_ * g0.w + b0.w);        \
+      pk_.z = pack2_h16<DT>((u1.x - mean_) * rstd_ * g1.x + b1.x, (u1.y - mean_) * rstd_ * g1.y + b1.y);        \
+      pk_.w = pack2_h16<DT>((u1.z - mean_) * rstd_ * g1.z + b1.z, (u1.w - mean_) * rstd_ * g1.w + b1.w);        \
+      *reinterpret_cast<uint4*>(dst_ + j * WSUB) = pk_;                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }                                                                                                           \
+  }
+  if constexpr (LNF) {
+    for (int i = tid; i < 2 * WK; i += WTHREADS) gb_s[i] = i < WK ? ln_g[i] : ln_b[i - WK];
+    if (loader) WS_STAGE_RAW(it0 % n_mt)
+    WS_BARRIER();                       // gamma / beta visible
+    if (loader) {
+      WS_LN_TRANSFORM(0)
+      if (it0 + 1 < it1) WS_STAGE_RAW((it0 + 1) % n_mt)      // (the transform's LDS reads are complete: it ends on writes
+    }                                                          //  that consumed them, and the DMA is issued after those)
+  } else {
+    if (loader) ws_stage(A, (int64_t)(it0 % n_mt) * WBM, rows, wave, voff_a, voff_b, ring_lds);
+  }
 
   for (int it = it0; it < it1;) {
   // ---- one 384-column panel: this wave's 32 weight rows, whole K, stay in registers for all its row tiles ----
@@ -148,7 +243,7 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
   for (; it < it_end; ++it) {
     const int par = (it - it0) & 1;
     const char* abuf = smem + par * WABYTES;
-    if (loader) {
+    if constexpr (!LNF) if (loader) {
       if (it + 1 < it1) {
         ws_stage(A, (int64_t)((it + 1) % n_mt) * WBM, rows, wave, voff_a, voff_b, ring_lds + (par ^ 1) * WABYTES);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 DMA pieces of the next tile
@@ -158,6 +253,16 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
     WS_BARRIER();   // the tile of this item is in LDS for everybody; the staging tile is free
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LNF) {
+      // Loader waves first normalise the NEXT tile (its raw rows were requested a whole tile ago) into ring[par ^ 1] --
+      // last read one tile ago, two barriers back -- and request the raw rows of the tile after it; the other two waves
+      // of each SIMD run their MFMAs meanwhile, the loader's own MFMAs follow in their shadow.
+      if (loader && it + 1 < it1) {
+        WS_LN_TRANSFORM(par ^ 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw rows have been read: the buffer may be overwritten
+        if (it + 2 < it1) WS_STAGE_RAW((it + 2) % n_mt)
+      }
+    }
 
     f32x16_t acc;
 #pragma unroll
@@ -211,10 +316,13 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
   WS_STORE(prev_m0, prev_n0)
 #undef WS_PACK
 #undef WS_STORE
+#undef WS_STAGE_RAW
+#undef WS_LN_TRANSFORM
 }
 
-template <int DT>
-int launch_ws(const void* a, const void* w, const float* bias, void* out, int64_t rows, int n, int epi, hipStream_t st) {
+template <int DT, bool LNF>
+int launch_ws(const void* a, const void* w, const float* bias, void* out, int64_t rows, int n, int epi, const float* ln_g,
+              const float* ln_b, float ln_eps, hipStream_t st) {
   static const int cus = [] {
     int dev = 0, v = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
@@ -223,12 +331,11 @@ int launch_ws(const void* a, const void* w, const float* bias, void* out, int64_
   const int n_mt = (int)((rows + WBM - 1) / WBM);
   const int total = n_mt * (n / WNT);
   const int grid = total < cus ? total : cus;
-  const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Wp = (const unsigned short*)w;
 #define VITTF_WS_CASE(E)                                                                                     \
   case E:                                                                                                    \
-    hipLaunchKernelGGL((gemm_ws_kernel<DT, E>), dim3(grid), dim3(WTHREADS), 0, st, A, Wp, bias,              \
-                       (unsigned short*)out, rows, n, n_mt, total);                                          \
+    hipLaunchKernelGGL((gemm_ws_kernel<DT, E, LNF>), dim3(grid), dim3(WTHREADS), 0, st, a, Wp, bias,         \
+                       (unsigned short*)out, rows, n, n_mt, total, ln_g, ln_b, ln_eps);                      \
     break;
   switch (epi) {
     VITTF_WS_CASE(VITTF_EPI_BIAS)
@@ -248,7 +355,19 @@ int vittf_gemm_ws(const void* a, const void* w, const float* bias, void* out, in
                   int32_t epilogue, int32_t dtype, hipStream_t st) {
   if (k != WK || n % WNT != 0) return 1;
   if ((rows + WBM - 1) / WBM * (n / WNT) > (1 << 30)) return 1;
-  if (dtype == VITTF_BF16) return launch_ws<VITTF_BF16>(a, w, bias, out, rows, n, epilogue, st);
-  if (dtype == VITTF_FP16) return launch_ws<VITTF_FP16>(a, w, bias, out, rows, n, epilogue, st);
+  if (dtype == VITTF_BF16) return launch_ws<VITTF_BF16, false>(a, w, bias, out, rows, n, epilogue, nullptr, nullptr, 0.f, st);
+  if (dtype == VITTF_FP16) return launch_ws<VITTF_FP16, false>(a, w, bias, out, rows, n, epilogue, nullptr, nullptr, 0.f, st);
   return VITTF_ERR_INVALID_ARG;
+}
+
+// LayerNorm fused into the activation loader (see LNF above): out = epilogue(LN(x) . W^T + bias), x fp32 [rows][384].
+extern "C" int vittf_ln_gemm(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const void* w,
+                             const float* bias, void* out, int64_t rows, int32_t n, int32_t k, int32_t epilogue,
+                             int32_t dtype, void* stream) {
+  if (!x || !ln_g || !ln_b || !w || !bias || !out || rows <= 0) return VITTF_ERR_INVALID_ARG;
+  if (k != WK || n <= 0 || n % WNT != 0 || (rows + WBM - 1) / WBM * (n / WNT) > (1 << 30)) return VITTF_ERR_INVALID_ARG;
+  int rc = VITTF_ERR_INVALID_ARG;
+  if (dtype == VITTF_BF16) rc = launch_ws<VITTF_BF16, true>(x, w, bias, out, rows, n, epilogue, ln_g, ln_b, ln_eps, (hipStream_t)stream);
+  if (dtype == VITTF_FP16) rc = launch_ws<VITTF_FP16, true>(x, w, bias, out, rows, n, epilogue, ln_g, ln_b, ln_eps, (hipStream_t)stream);
+  return rc == 1 ? VITTF_ERR_INVALID_ARG : rc;
 }
