@@ -119,9 +119,10 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   { ProfScope ps(VITTF_KERNEL_PATCH_EMBED, stream); rc = vittf_patch_embed(cfg, w, pos, view, slice0, batch, X, stream); }
   if (rc) return rc;
   const size_t esz = 2;
-  // ViT-S: LayerNorm is computed inside the qkv / fc1 GEMMs' activation loader (vittf_ln_gemm); VITTF_LN_FUSED=0 keeps
-  // the separate LayerNorm launches
-  static const bool ln_fused_env = [] { const char* e = getenv("VITTF_LN_FUSED"); return !e || atoi(e) != 0; }();
+  // ViT-S, opt-in (VITTF_LN_FUSED=1): LayerNorm computed inside the qkv / fc1 GEMMs' activation loader (vittf_ln_gemm).
+  // Parity-green, but the fp32 rows are then fetched once per 384-column panel (3-4 x 201 MB instead of 3-4 x 100 MB of
+  // 16-bit rows), which costs what the LayerNorm launches cost: +1 % on the 64^3 workload, +-0 on 256^3.
+  static const bool ln_fused_env = [] { const char* e = getenv("VITTF_LN_FUSED"); return e && atoi(e) != 0; }();
   const bool ln_fused = ln_fused_env && d == 384 && !(w->fc2_w_perm);
   for (int l = 0; l < L; ++l) {
     const char* qkv_w = (const char*)w->qkv_w + (size_t)l * 3 * d * d * esz;
