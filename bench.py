@@ -170,7 +170,9 @@ def main():
         step()
     torch.cuda.synchronize()
     barrier()
-    vt._lib.profiler_enable(True)
+    # HIP events around the launches of the dominant kernel only (attention, ~50 % of the kernel time): bracketing every
+    # launch costs 2-3 % of the throughput.  The other classes are timed in one extra, untimed step below.
+    vt._lib.profiler_enable(True, classes=None if os.environ.get('VITTF_BENCH_FULLPROF') == '1' else ['attention'])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -179,7 +181,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = vt._lib.profiler_collect()
+    vt._lib.profiler_enable(True)                       # all classes, one step outside the timed region
+    step()
+    torch.cuda.synchronize()
+    prof_all = vt._lib.profiler_collect()
     vt._lib.profiler_enable(False)
+    for k, (ms, n) in prof_all.items():
+        if k != 'attention':
+            prof[k] = (ms * args.steps, n * args.steps)  # scaled to the timed steps (same launches every step)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -212,6 +221,7 @@ def main():
         'launches': int(dom_launches), 'avg_launch_ms': round(dom_ms / max(1, dom_launches), 4),
         'flop_per_launch': flops[dom] / max(1, dom_launches),
         'kernel_ms_rank0': {k: round(v[0], 2) for k, v in prof.items()},
+        'kernel_ms_note': 'attention: events inside the timed steps; other classes: one extra untimed step x steps',
         'whole_vit_tflops': round((attn_f + lin_f + mlp_f + pe_f) * slices_done / (sum(v[0] for v in prof.values()) * 1e-3) / 1e12, 2)
         if sum(v[0] for v in prof.values()) > 0 else 0.0,
     }

@@ -127,14 +127,15 @@ int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit_weights* w
 
 /* Optional timing of the launches inside vittf_vit_k_features, by kernel class, with HIP events recorded on
  * the caller's stream (what bench.py's roofline leg reads).  Process-global, off by default, not thread-safe:
- * the one exception to "no global mutable state".  enable(1) clears earlier records and starts recording,
- * enable(0) stops; collect() waits for the recorded events and returns, per class, the summed launch
+ * the one exception to "no global mutable state".  enable(mask) clears earlier records and starts recording the
+ * classes whose bit (1 << vittf_kernel_class) is set (-1: all; two event records per launch cost ~2-3 % of the
+ * throughput when every launch is bracketed, so bench.py times with the dominant class only), enable(0) stops; collect() waits for the recorded events and returns, per class, the summed launch
  * durations in ms and the launch counts (arrays of VITTF_KERNEL_CLASSES entries, [host]). */
 typedef enum vittf_kernel_class {
   VITTF_KERNEL_PATCH_EMBED = 0, VITTF_KERNEL_LAYERNORM = 1, VITTF_KERNEL_GEMM = 2, VITTF_KERNEL_ATTENTION = 3,
   VITTF_KERNEL_MLP = 4, VITTF_KERNEL_CLASSES = 5
 } vittf_kernel_class;
-int vittf_profiler_enable(int32_t on);
+int vittf_profiler_enable(int32_t class_mask);
 int vittf_profiler_collect(double* ms_per_class, int64_t* launches_per_class);
 
 /* ------------------------------------------------------------------------------------------

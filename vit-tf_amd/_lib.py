@@ -112,8 +112,12 @@ def load():
 KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention', 'mlp')
 
 
-def profiler_enable(on=True):
-    check(load().vittf_profiler_enable(int(bool(on))), 'vittf_profiler_enable')
+def profiler_enable(on=True, classes=None):
+    """Record HIP events around the engine's launches: all kernel classes, or only `classes` (names of KERNEL_CLASSES)."""
+    mask = 0
+    if on:
+        mask = -1 if classes is None else sum(1 << KERNEL_CLASSES.index(c) for c in classes)
+    check(load().vittf_profiler_enable(mask), 'vittf_profiler_enable')
 
 
 def profiler_collect():

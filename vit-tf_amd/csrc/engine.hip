@@ -20,7 +20,7 @@ namespace {
 // ---- optional per-kernel-class timing with HIP events on the caller's stream (bench.py's roofline leg) ----
 // Process-global and off by default; the only mutable state in the library.  Not thread-safe.
 struct ProfRec { hipEvent_t a, b; int cls; };
-bool g_prof_on = false;
+unsigned g_prof_mask = 0;   // bit per kernel class
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 
@@ -33,7 +33,7 @@ hipEvent_t prof_event() {
 
 struct ProfScope {
   ProfRec r; hipStream_t st; bool on;
-  ProfScope(int cls, void* stream) : st((hipStream_t)stream), on(g_prof_on) {
+  ProfScope(int cls, void* stream) : st((hipStream_t)stream), on((g_prof_mask >> cls) & 1u) {
     if (on) { r.cls = cls; r.a = prof_event(); r.b = prof_event(); (void)hipEventRecord(r.a, st); }
   }
   ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof_recs.push_back(r); } }
@@ -190,7 +190,7 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
 extern "C" int vittf_profiler_enable(int32_t on) {
   for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
   g_prof_recs.clear();
-  g_prof_on = on != 0;
+  g_prof_mask = (unsigned)on;
   return VITTF_OK;
 }
 
