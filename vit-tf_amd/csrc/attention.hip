@@ -168,7 +168,7 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
 }
 
 template <int DT, bool PRE>
-__global__ __launch_bounds__(256, PRE ? 2 : 4) void attn_kernel(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned short* __restrict__ qkv,
                                                       unsigned short* __restrict__ out, int tokens, int heads,
                                                       int q_tiles, int total, float c) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];  // [buffer][K | V]
