@@ -94,8 +94,8 @@ __device__ __forceinline__ float gelu_poly(float x) {
   p = fmaf(p, z, -0.148780614f);
   p = fmaf(p, z, -0.918451846f);
   p = fmaf(p, z, -1.6278975f);
-  const float r = x * __builtin_amdgcn_exp2f(fmaf(p, z, -1.0f));   // 0.5 x erfc(z)
-  return x >= 0.f ? x - r : r;
+  const float e = __builtin_amdgcn_exp2f(fmaf(p, z, -1.0f));   // 0.5 erfc(z)
+  return fmaf(-fabsf(x), e, fmaxf(x, 0.f));                    // max(x, 0) - |x| 0.5 erfc(|x| / sqrt 2): both signs, 9 VALU
 }
 
 // ---- LDS-DMA hidden from hipcc -------------------------------------------------------------------------------
