@@ -47,7 +47,7 @@ def main():
         fl = batch * 4 * tokens * tokens * d
         print(f'attention  (q_prescaled={pre}) batch {batch} N {tokens}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({fl / ms / 1e9 / 25:.1f} % of 2.5 PF)')
     if 'gemm' in what:
-        for name, n, k, epi in (('qkv', 3 * d, d, 0), ('proj+res', d, d, 2), ('fc1+gelu', 4 * d, d, 1), ('fc2+res', d, 4 * d, 2), ('kfeat', d, d, 3)):
+        for name, n, k, epi in (('qkv', 3 * d, d, 0), ('qkv+qscale', 3 * d, d, 4), ('proj+res', d, d, 2), ('fc1+gelu', 4 * d, d, 1), ('fc2+res', d, 4 * d, 2), ('kfeat', d, d, 3)):
             a = torch.randn(rows, k, generator=g).to(TDT[dt]).to(dev)
             w = (torch.randn(n, k, generator=g) / k ** 0.5).to(TDT[dt]).to(dev)
             bias = torch.randn(n, generator=g).to(dev)

@@ -115,11 +115,16 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
 
   // pack `prev` into the staging tile ...
 #define WS_PACK()                                                                                               \
-  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                               \
-    uint2 pk;                                                                                                   \
-    pk.x = pack2_h16<DT>(prev[4 * g + 0], prev[4 * g + 1]);                                                     \
-    pk.y = pack2_h16<DT>(prev[4 * g + 2], prev[4 * g + 3]);                                                     \
-    *reinterpret_cast<uint2*>(cbuf + l31 * WCS + (32 * wave + 8 * g + 4 * h) * 2) = pk;                         \
+  {                                                                                                             \
+    int ln_ = lane;                                                                                             \
+    asm volatile("" : "+v"(ln_));   /* lane-derived offsets are recomputed per tile: as loop invariants they get spilled, */ \
+    const int pk_off_ = (ln_ & 31) * WCS + (32 * wave + 4 * (ln_ >> 5)) * 2;   /* and a scratch reload drains vmcnt */ \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                             \
+      uint2 pk;                                                                                                 \
+      pk.x = pack2_h16<DT>(prev[4 * g + 0], prev[4 * g + 1]);                                                   \
+      pk.y = pack2_h16<DT>(prev[4 * g + 2], prev[4 * g + 3]);                                                   \
+      *reinterpret_cast<uint2*>(cbuf + pk_off_ + 16 * g) = pk;                                                  \
+    }                                                                                                           \
   }
   // ... and (after a barrier) the storer waves write the tile (M0, N0) as whole row segments; rows past the end
   // fall outside the descriptor and are dropped by the hardware
@@ -290,9 +295,12 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
     // 32 wave + 8 g + 4 h + {0..3}); every read of the panel's bias happens before the barrier below
     const bool pending = prev_n0 >= 0;
     WS_PACK()   // unconditional (the staging tile is free): keeps the activation above inside the MFMA loop
+    int lb_ = lane;
+    asm volatile("" : "+v"(lb_));
+    const float* bias_w = bias_l + 32 * wave + 4 * (lb_ >> 5);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 bv = *reinterpret_cast<const float4*>(bias_l + 32 * wave + 8 * g + 4 * h);
+      const float4 bv = *reinterpret_cast<const float4*>(bias_w + 8 * g);
       prev[4 * g + 0] = (acc[4 * g + 0] + bv.x) * qsc;
       prev[4 * g + 1] = (acc[4 * g + 1] + bv.y) * qsc;
       prev[4 * g + 2] = (acc[4 * g + 2] + bv.z) * qsc;
