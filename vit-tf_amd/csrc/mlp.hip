@@ -72,7 +72,8 @@ __device__ __forceinline__ void issue_tile(int seq, const unsigned short* __rest
     int row, c;
     tile_pos(q, row, c);
     const unsigned short* g = src + (int64_t)row * ld + c * 8;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(slot + ((i * 256 + (tid & ~63)) << 4)), 16, 0, 0);
+    // (asm piece, see lds_dma16: with the builtin hipcc added its own, stricter vmcnt waits in front of the fragment reads)
+    lds_dma16_flat(g, (unsigned)(size_t)LDS_PTR(slot) + ((i * 256 + __builtin_amdgcn_readfirstlane(tid & ~63)) << 4));
   }
 }
 

@@ -121,6 +121,13 @@ __device__ __forceinline__ void lds_dma16(i32x4_t rsrc, unsigned lds_addr, int v
                : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// the same with a per-lane 64-bit global address instead of a buffer descriptor
+__device__ __forceinline__ void lds_dma16_flat(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+
 static inline int vittf_check_launch() {
   return hipGetLastError() == hipSuccess ? VITTF_OK : VITTF_ERR_LAUNCH;
 }
