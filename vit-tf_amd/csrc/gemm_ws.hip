@@ -74,13 +74,14 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
   __shared__ __attribute__((aligned(16))) float gb_s[LNF ? 2 * WK : 4];         // LNF: gamma | beta
   // Separate LDS objects on purpose: hipcc orders ds_write / ds_read against outstanding LDS-DMA with vmcnt(0)
   // unless alias scopes (one per LDS variable) prove that they touch different memory.
-  __shared__ __attribute__((aligned(16))) char smem[2 * WABYTES];    // the two activation tiles (LDS-DMA targets)
-  __shared__ __attribute__((aligned(16))) char cbuf[WCBYTES];        // staging tile
-  __shared__ __attribute__((aligned(16))) float bias_s[WNT];         // the panel's bias
+  constexpr int RING = LNF ? 2 : 3;    // activation tiles in the ring: with one barrier per tile the DMA of a tile can only be
+                                       // issued after the barrier behind the last reader of its slot; depth 3 gives it two tiles to land
+  __shared__ __attribute__((aligned(16))) char smem[RING * WABYTES];    // the activation ring (LDS-DMA targets)
+  __shared__ __attribute__((aligned(16))) char cbuf2[2 * WCBYTES];   // two staging tiles (packed one tile, stored the next)
+  __shared__ __attribute__((aligned(16))) float bias_s2[2 * WNT];    // the panel's bias, by panel parity
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
   const int h = lane >> 5, l31 = lane & 31;
-  const float* const bias_l = bias_s;
 
   // Work split: items = (panel, row tile), panel-major, contiguous balanced ranges.  (Giving the P panels of one range
   // of row tiles to P workgroups of one XCD, so that an activation tile is fetched from HBM once, measured slower:
@@ -112,9 +113,11 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
   for (int i = 0; i < 16; ++i) prev[i] = 0.f;
   int64_t prev_m0 = 0;
   int prev_n0 = -1;            // -1: nothing pending
+  int64_t st_m0 = 0;           // the tile packed into the staging slot last iteration, stored after the next barrier
+  int st_n0 = -1;
 
   // pack `prev` into the staging tile ...
-#define WS_PACK()                                                                                               \
+#define WS_PACK(SLOT)                                                                                           \
   {                                                                                                             \
     int ln_ = lane;                                                                                             \
     asm volatile("" : "+v"(ln_));   /* lane-derived offsets are recomputed per tile: as loop invariants they get spilled, */ \
@@ -123,12 +126,12 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
       uint2 pk;                                                                                                 \
       pk.x = pack2_h16<DT>(prev[4 * g + 0], prev[4 * g + 1]);                                                   \
       pk.y = pack2_h16<DT>(prev[4 * g + 2], prev[4 * g + 3]);                                                   \
-      *reinterpret_cast<uint2*>(cbuf + pk_off_ + 16 * g) = pk;                                                  \
+      *reinterpret_cast<uint2*>(cbuf2 + (SLOT) * WCBYTES + pk_off_ + 16 * g) = pk;                              \
     }                                                                                                           \
   }
   // ... and (after a barrier) the storer waves write the tile (M0, N0) as whole row segments; rows past the end
   // fall outside the descriptor and are dropped by the hardware
-#define WS_STORE(M0, N0)                                                                                        \
+#define WS_STORE(M0, N0, SLOT)                                                                                  \
   if (storer) {                                                                                                 \
     int ts_ = tid - 384;                              /* storer thread index (waves 6..11) */                   \
     asm volatile("" : "+v"(ts_));                     /* (recomputed per tile: see WS_LN_TRANSFORM) */          \
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
     const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(                                                       \
         o16, 0, (int)(left < (int64_t)WBM * n * 2 ? left : (int64_t)WBM * n * 2), 0x00020000);                  \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
-      const u32x4_t d = *reinterpret_cast<const u32x4_t*>(cbuf + st_lds + i * (8 * WCS));                       \
+      const u32x4_t d = *reinterpret_cast<const u32x4_t*>(cbuf2 + (SLOT) * WCBYTES + st_lds + i * (8 * WCS));   \
       __builtin_amdgcn_raw_buffer_store_b128(d, orsrc, st_glb, i * 16 * n, 0);                                  \
     }                                                                                                           \
   }
@@ -226,7 +229,10 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
       if (it0 + 1 < it1) WS_STAGE_RAW((it0 + 1) % n_mt)      // (the transform's LDS reads are complete: it ends on writes
     }                                                          //  that consumed them, and the DMA is issued after those)
   } else {
-    if (loader) ws_stage(A, (int64_t)(it0 % n_mt) * WBM, rows, wave, voff_a, voff_b, ring_lds);
+    if (loader) {
+      ws_stage(A, (int64_t)(it0 % n_mt) * WBM, rows, wave, voff_a, voff_b, ring_lds);
+      if (it0 + 1 < it1) ws_stage(A, (int64_t)((it0 + 1) % n_mt) * WBM, rows, wave, voff_a, voff_b, ring_lds + WABYTES);
+    }
   }
 
   for (int it = it0; it < it1;) {
@@ -240,24 +246,32 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
     for (int s = 0; s < WKS; ++s) wf[s] = *reinterpret_cast<const s16x8_t*>(wrow + 16 * s);
     // the bias goes through LDS: a global load inside the loop would make hipcc drain vmcnt (stores + next DMA).
-    // Its last readers (the previous panel's tiles) are behind a barrier; visible after the next barrier.
-    if (tid < WNT / 4) reinterpret_cast<float4*>(bias_s)[tid] = reinterpret_cast<const float4*>(bias + n0)[tid];
+    // Two copies by panel parity: a wave may still hand over the previous panel's last tile; visible after the next barrier.
+    if (tid < WNT / 4) reinterpret_cast<float4*>(bias_s2 + (nt & 1) * WNT)[tid] = reinterpret_cast<const float4*>(bias + n0)[tid];
   }
   // the q third carries the softmax scale and the exp -> exp2 base change: one rounding, like plain q
   const float qsc = (EPI == VITTF_EPI_BIAS_QKV && n0 + 32 * wave < n / 3) ? 0.125f * 1.44269504088896340736f : 1.0f;
   for (; it < it_end; ++it) {
-    const int par = (it - it0) & 1;
+    const int par = (it - it0) % RING;
     const char* abuf = smem + par * WABYTES;
-    if constexpr (!LNF) if (loader) {
-      if (it + 1 < it1) {
-        ws_stage(A, (int64_t)((it + 1) % n_mt) * WBM, rows, wave, voff_a, voff_b, ring_lds + (par ^ 1) * WABYTES);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 DMA pieces of the next tile
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!LNF) {
+      // this tile's DMA pieces (issued two tiles ago) have landed; the next tile's 4 pieces may still be in flight
+      if (loader) {
+        if (it + 1 < it1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
-    WS_BARRIER();   // the tile of this item is in LDS for everybody; the staging tile is free
+    WS_BARRIER();   // the ONE barrier per tile: this tile's operands are in LDS for everybody, and so is the staging
+                    // slot packed during the previous tile, which the storer waves now send off (the other waves go on)
     __builtin_amdgcn_sched_barrier(0);
+    const int slot = (it - it0) & 1;
+    if constexpr (!LNF) {
+      // the DMA of tile it + 2 goes out only now: its ring slot was read by the MFMAs of tile it - 1, and with one
+      // barrier per tile a slow wave is still in them until it reaches the barrier above
+      if (loader && it + 2 < it1)
+        ws_stage(A, (int64_t)((it + 2) % n_mt) * WBM, rows, wave, voff_a, voff_b, ring_lds + ((par + 2) % RING) * WABYTES);
+    }
+    if (st_n0 >= 0) WS_STORE(st_m0, st_n0, slot ^ 1)
     if constexpr (LNF) {
       // Loader waves first normalise the NEXT tile (its raw rows were requested a whole tile ago) into ring[par ^ 1] --
       // last read one tile ago, two barriers back -- and request the raw rows of the tile after it; the other two waves
@@ -293,11 +307,12 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
 
     // tile t - 1 -> staging; accumulators of tile t -> prev (the lane owns activation row l31 and output columns
     // 32 wave + 8 g + 4 h + {0..3}); every read of the panel's bias happens before the barrier below
-    const bool pending = prev_n0 >= 0;
-    WS_PACK()   // unconditional (the staging tile is free): keeps the activation above inside the MFMA loop
+    WS_PACK(slot)   // (also when nothing is pending: keeps the activation above inside the MFMA loop; never stored then)
+    st_m0 = prev_m0;
+    st_n0 = prev_n0;
     int lb_ = lane;
     asm volatile("" : "+v"(lb_));
-    const float* bias_w = bias_l + 32 * wave + 4 * (lb_ >> 5);
+    const float* bias_w = bias_s2 + (nt & 1) * WNT + 32 * wave + 4 * (lb_ >> 5);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 bv = *reinterpret_cast<const float4*>(bias_w + 8 * g);
@@ -306,22 +321,22 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
       prev[4 * g + 2] = (acc[4 * g + 2] + bv.z) * qsc;
       prev[4 * g + 3] = (acc[4 * g + 3] + bv.w) * qsc;
     }
-    WS_BARRIER();
-    if (pending) WS_STORE(prev_m0, prev_n0)
     prev_m0 = (int64_t)(it - nt * n_mt) * WBM;
     prev_n0 = n0;
   }   // row tiles of the panel
   }   // panels
 
-  // the last tile: its activation was not overlapped with anything
+  // drain: the tile packed in the last iteration, then the last tile itself (its activation overlapped with nothing)
+  const int last_slot = (it1 - 1 - it0) & 1;
+  WS_BARRIER();
+  if (st_n0 >= 0) WS_STORE(st_m0, st_n0, last_slot)
   if constexpr (EPI == VITTF_EPI_BIAS_GELU) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) prev[s] = gelu_poly(prev[s]);
   }
-  WS_BARRIER();   // the previous tile's readers of the staging tile
-  WS_PACK()
+  WS_PACK(last_slot ^ 1)
   WS_BARRIER();
-  WS_STORE(prev_m0, prev_n0)
+  WS_STORE(prev_m0, prev_n0, last_slot ^ 1)
 #undef WS_PACK
 #undef WS_STORE
 #undef WS_STAGE_RAW
