@@ -14,6 +14,7 @@
 //     the in-lane sum over the 16 query rows a lane holds; one barrier per chunk.
 #include "vittf_common.h"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -136,7 +137,8 @@ int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, con
                         int32_t classes, const float* voxel_norm, float* sim, unsigned* maxbits, void* ws, size_t ws_bytes,
                         hipStream_t st) {
   const int total_a = class_start_host[classes];
-  if (f != SM_F || total_a < 64) return 1;
+  static const int min_a = [] { const char* e = getenv("VITTF_SIM_MFMA_MIN"); return e ? atoi(e) : 64; }();
+  if (f != SM_F || total_a < min_a) return 1;
   if (!ws || ws_bytes < vittf_sim_mfma_workspace_bytes(classes, total_a)) return 1;
   std::vector<int> src_row, chunk_start(classes + 1, 0);
   std::vector<float> counts(classes);

@@ -301,7 +301,7 @@ SimWs sim_ws_layout(int32_t classes, int64_t nvox, int32_t annotations) {
   L.maxbits = 0;
   L.qf_t = align256((size_t)classes * 4);
   L.mfma = L.qf_t + align256((size_t)4096 * ACH * 4);
-  L.mfma_bytes = annotations >= 64 ? align256(vittf_sim_mfma_workspace_bytes(classes, annotations)) : 0;
+  L.mfma_bytes = annotations >= 1 ? align256(vittf_sim_mfma_workspace_bytes(classes, annotations)) : 0;
   L.maps = L.mfma + L.mfma_bytes;
   L.total = L.maps + (size_t)classes * (size_t)nvox * 4;
   return L;
