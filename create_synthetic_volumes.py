@@ -13,10 +13,10 @@ NAMES = ('sphere_thick', 'sphere_filled', 'torus_thick', 'torus_filled')
 
 def main(argv=None):
     parser = ArgumentParser()
-    parser.add_argument('outdir', type=Path, help='Output directory')
-    parser.add_argument('--size', type=int, default=128, help='Volume size')
-    parser.add_argument('--noise', type=float, default=0.0, help='Noise standard deviation')
-    parser.add_argument('--torch', action='store_true', help='Save as torch tensors (.pt files)')
+    parser.add_argument('outdir', type=Path, help='directory the .npy / .pt files are written to')
+    parser.add_argument('--size', type=int, default=128, help='edge length N of the N^3 volumes')
+    parser.add_argument('--noise', type=float, default=0.0, help='sigma of the additive Gaussian noise')
+    parser.add_argument('--torch', action='store_true', help='write torch .pt files instead of .npy')
     parser.add_argument('--seed', type=int, default=0, help='Noise seed')
     args = parser.parse_args(argv)
     outdir = Path(args.outdir)

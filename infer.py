@@ -221,17 +221,17 @@ def main(argv=None):
     dino_archs = ['vits16', 'vits8', 'vitb16', 'vitb8']
     dino2_archs = ['vits14', 'vitb14', 'vitl14', 'vitg14']
     parser = ArgumentParser('Infer DINO features from saved volume')
-    parser.add_argument('--data-path', type=str, required=True, help='Path to the saved volume')
-    parser.add_argument('--cache-path', type=str, default=None, help='Path to save computed qkv features to.')
-    parser.add_argument('--dino-model', type=str, choices=dino_archs, default=None, help='DINO model to use')
-    parser.add_argument('--dino2-model', type=str, choices=dino2_archs, default=None, help='DINOv2 model to use')
+    parser.add_argument('--data-path', type=str, required=True, help='volume file (.npy / .pt) to extract features from')
+    parser.add_argument('--cache-path', type=str, default=None, help='where the feature file goes (default: next to the volume)')
+    parser.add_argument('--dino-model', type=str, choices=dino_archs, default=None, help='DINO ViT variant')
+    parser.add_argument('--dino2-model', type=str, choices=dino2_archs, default=None, help='DINOv2 variant (not available offline)')
     parser.add_argument('--slice-along', type=str, choices=['x', 'y', 'z', 'all'], default='all',
                         help='Along which axis to slice volume, as it is fed slice-wise to DINO')
-    parser.add_argument('--batch-size', type=int, default=1, help='Feed volume through network in batches')
+    parser.add_argument('--batch-size', type=int, default=1, help='accepted for compatibility; the engine batches slices itself')
     parser.add_argument('--feature-output-size', type=int, default=64,
                         help='Produces a features map with aspect ratio of input volume with this value as y resolution. Only if --slice-along ALL')
     parser.add_argument('--cpu', action='store_true', help='Use CPU only (not available in the MI355X build)')
-    parser.add_argument('--overwrite', action='store_true', help='Overwrite existing cache files')
+    parser.add_argument('--overwrite', action='store_true', help='replace an existing feature file')
     # additions of the MI355X build
     parser.add_argument('--weights', type=str, default=None, help='Local DINO state dict (.pth)')
     parser.add_argument('--synthetic-weights', type=int, default=None, metavar='SEED', help='Use seeded synthetic weights')

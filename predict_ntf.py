@@ -73,11 +73,11 @@ def _metrics(labels, pred, names):
 
 def main(argv=None):
     parser = ArgumentParser()
-    parser.add_argument('--data', type=str, help='Path to features, annotations, volume etc.')
-    parser.add_argument('--bilateral-solver', action='store_true', help='Use bilateral solver')
-    parser.add_argument('--load-sims', action='store_true', help='Load similarities from file')
-    parser.add_argument('--num-samples', type=float, default=0.0, help='Number of samples to use for each NTF')
-    parser.add_argument('--sampling-mode', type=str, choices=['uniform', 'surface', 'both'], default='both', help='Sampling mode')
+    parser.add_argument('--data', type=str, help='directory holding volume, features and annotations / labels')
+    parser.add_argument('--bilateral-solver', action='store_true', help='refine every class map with the 3-D bilateral solver')
+    parser.add_argument('--load-sims', action='store_true', help='reuse a similarities file written by an earlier run')
+    parser.add_argument('--num-samples', type=float, default=0.0, help='annotations sampled per class from the labels (0: use the annotation file)')
+    parser.add_argument('--sampling-mode', type=str, choices=['uniform', 'surface', 'both'], default='both', help='where samples are drawn from')
     parser.add_argument('--gpu', action='store_true', help='Use GPU (always on in this build)')
     args = parser.parse_args(argv)
     d = Path(args.data)
