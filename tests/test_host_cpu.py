@@ -40,7 +40,7 @@ def test_workspace_query_and_argument_validation_need_no_gpu():
     assert lib.vittf_vit_workspace_bytes(ctypes.byref(bad), 1, 4097) == 0
     assert lib.vittf_gemm(None, None, None, None, 1, 128, 64, 0, 0, 0, None) == -1
     assert lib.vittf_similarity_workspace_bytes(2, 64 ** 3, 16) >= 2 * 64 ** 3 * 4
-    assert lib.vittf_similarity_workspace_bytes(5, 64 ** 3, 5120) > lib.vittf_similarity_workspace_bytes(5, 64 ** 3, 16) + 5120 * 384 * 4
+    assert lib.vittf_similarity_workspace_bytes(5, 64 ** 3, 5120) > lib.vittf_similarity_workspace_bytes(5, 64 ** 3, 16) + 5000 * 384 * 4
 
 
 def test_product_refuses_to_run_without_gpu():
