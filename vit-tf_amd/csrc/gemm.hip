@@ -20,6 +20,10 @@
 
 namespace {
 
+// LDS-only synchronisation for the epilogue: __syncthreads() also drains vmcnt(0), i.e. the residual read-modify-write
+// of the first half tile would be waited for before the second half is even staged
+#define GEMM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KB
 
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_kernel(const un
     float* xo = reinterpret_cast<float*>(out);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      if (half) __syncthreads();
+      if (half) GEMM_LDS_BARRIER();
       if (wn == half) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_kernel(const un
           }
         }
       }
-      __syncthreads();
+      GEMM_LDS_BARRIER();
 #pragma unroll
       for (int pass = 0; pass < 8; ++pass) {
         const int rl = pass * 16 + (tid >> 4);
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_kernel(const un
         }
       }
     }
-    __syncthreads();
+    GEMM_LDS_BARRIER();
     unsigned short* o16 = reinterpret_cast<unsigned short*>(out);
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
