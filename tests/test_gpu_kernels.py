@@ -433,7 +433,8 @@ def test_bilateral_e2e_golden(gpu, golden_dir):
         assert _u8_close(got[k], ref), k
 
 
-@pytest.mark.parametrize('shape,sim_shape', [((40, 36, 44), (20, 18, 22)), ((30, 30, 30), (30, 30, 30)), ((17, 50, 23), (31, 25, 40))])
+@pytest.mark.parametrize('shape,sim_shape', [((40, 36, 44), (20, 18, 22)), ((30, 30, 30), (30, 30, 30)), ((17, 50, 23), (31, 25, 40)),
+                                             ((200, 160, 224), (100, 80, 112))])
 def test_bilateral_refine_vs_oracle(gpu, shape, sim_shape):
     """refine_similarity (resizes, uint8 reference, crop, Sobel confidence, grid, bistochastisation, PCG, slice) against
     the CPU restatement at sizes with several spatial bins per axis, fp32 output compared directly."""
