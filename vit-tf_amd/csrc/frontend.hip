@@ -62,13 +62,13 @@ __global__ __launch_bounds__(256) void minmax_final(const float* __restrict__ pa
 constexpr int TP = 32;
 
 template <int P>
-__global__ __launch_bounds__(256) void patch_embed_kernel(vittf_slice_view view, int slice0, const float* __restrict__ w_t,
+__global__ __launch_bounds__(384) void patch_embed_kernel(vittf_slice_view view, int slice0, const float* __restrict__ w_t,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ cls_pos0,
                                                           const float* __restrict__ patch_pos, float* __restrict__ tokens_out,
                                                           int d, int f0, int f1) {
   constexpr int PP = P * P;
-  __shared__ float px[TP][PP + 1];
+  __shared__ __attribute__((aligned(16))) float px[TP][PP + 4];   // row stride 16-byte aligned: phase 2 reads float4 along k
   const int npatch = f0 * f1;
   const int tokens = npatch + 1;
   const int b = blockIdx.y;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(vittf_slice_view view,
   const float sc = (float)view.in_cols / (float)view.out_cols;
   const float* slice = view.vol + (int64_t)(slice0 + b) * view.stride_slice;
 
-  for (int e = threadIdx.x; e < TP * PP; e += 256) {
+  for (int e = threadIdx.x; e < TP * PP; e += blockDim.x) {
     const int pl = e / PP, k = e - pl * PP;
     const int p = p0 + pl;
     float v = 0.f;
@@ -99,14 +99,23 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(vittf_slice_view view,
   __syncthreads();
 
   float* out_b = tokens_out + (int64_t)b * tokens * d;
-  for (int dd = threadIdx.x; dd < d; dd += 256) {
+  for (int dd = threadIdx.x; dd < d; dd += blockDim.x) {
     float acc[TP];
 #pragma unroll
     for (int i = 0; i < TP; ++i) acc[i] = 0.f;
-    for (int k = 0; k < PP; ++k) {
-      const float wv = w_t[(int64_t)k * d + dd];
+    // four k per step: one 16-byte LDS broadcast read per patch instead of four 4-byte ones (the loop was LDS-issue
+    // bound); every accumulator still sums its products in ascending k, so the result is bit-identical
+    for (int k = 0; k < PP; k += 4) {
+      const float w0 = w_t[(int64_t)k * d + dd], w1 = w_t[(int64_t)(k + 1) * d + dd];
+      const float w2 = w_t[(int64_t)(k + 2) * d + dd], w3 = w_t[(int64_t)(k + 3) * d + dd];
 #pragma unroll
-      for (int i = 0; i < TP; ++i) acc[i] = fmaf(px[i][k], wv, acc[i]);
+      for (int i = 0; i < TP; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(&px[i][k]);
+        acc[i] = fmaf(v.x, w0, acc[i]);
+        acc[i] = fmaf(v.y, w1, acc[i]);
+        acc[i] = fmaf(v.z, w2, acc[i]);
+        acc[i] = fmaf(v.w, w3, acc[i]);
+      }
     }
     const float bv = bias[dd];
 #pragma unroll
@@ -148,11 +157,12 @@ extern "C" int vittf_patch_embed(const vittf_vit_config* cfg, const vittf_vit_we
   const int f0 = view->out_rows / p, f1 = view->out_cols / p;
   const int nblk = (f0 * f1 + TP - 1) / TP;
   hipStream_t st = (hipStream_t)stream;
+  const int threads = cfg->embed_dim % 384 == 0 ? 384 : 256;   // one feature per thread in a single pass for D = 384 / 768
   if (p == 8) {
-    hipLaunchKernelGGL((patch_embed_kernel<8>), dim3(nblk, batch), dim3(256), 0, st, *view, slice0, w->pe_w_t, w->pe_b,
+    hipLaunchKernelGGL((patch_embed_kernel<8>), dim3(nblk, batch), dim3(threads), 0, st, *view, slice0, w->pe_w_t, w->pe_b,
                        pos->cls_plus_pos0, pos->patch_pos, tokens_out, cfg->embed_dim, f0, f1);
   } else {
-    hipLaunchKernelGGL((patch_embed_kernel<16>), dim3(nblk, batch), dim3(256), 0, st, *view, slice0, w->pe_w_t, w->pe_b,
+    hipLaunchKernelGGL((patch_embed_kernel<16>), dim3(nblk, batch), dim3(threads), 0, st, *view, slice0, w->pe_w_t, w->pe_b,
                        pos->cls_plus_pos0, pos->patch_pos, tokens_out, cfg->embed_dim, f0, f1);
   }
   return vittf_check_launch();
