@@ -167,6 +167,13 @@ typedef enum vittf_epilogue {
 int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
                int32_t epilogue, int32_t tokens, int32_t dtype, void* stream);
 
+/* Residual linear + the LayerNorm that follows it:  x[rows][n] (fp32) += a[rows][k] . w[n][k]^T + bias;
+ * h[rows][n] (h16) = LayerNorm(x; ln_g, ln_b, ln_eps).  Replaces attn.proj + residual + norm2 and mlp.fc2 + residual +
+ * the next block's norm1.  For n = 384 (ViT-S) the LayerNorm is computed in the epilogue of a whole-row GEMM; other
+ * shapes run vittf_gemm(BIAS_RESIDUAL) + vittf_layernorm. */
+int vittf_gemm_residual_ln(const void* a, const void* w, const float* bias, float* x, int64_t rows, int32_t n, int32_t k,
+                           int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h, void* stream);
+
 /* LayerNorm fused into the weight-stationary GEMM (K = 384 only): out = epilogue(LayerNorm(x; g, b, eps) . W^T + bias),
  * x fp32 [rows][384] (the residual stream), epilogue VITTF_EPI_BIAS / _BIAS_GELU / _BIAS_QKV, 16-bit out [rows][n],
  * n % 384 == 0.  Replaces norm1 + attn.qkv and norm2 + mlp.fc1 of a block without the 16-bit LayerNorm tensor ever

@@ -69,7 +69,7 @@ def test_gemm_bias_and_gelu(gpu, dt, rows, n, k):
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-@pytest.mark.parametrize('rows,n,k', [(3, 128, 64), (515, 384, 384), (200, 384, 1536), (33000, 384, 384)])
+@pytest.mark.parametrize('rows,n,k', [(3, 128, 64), (515, 384, 384), (200, 384, 1536), (33000, 384, 384), (1030, 384, 1536), (256, 384, 64)])
 def test_gemm_residual(gpu, dt, rows, n, k):
     lib = _lib.load()
     a, w, bias, ref = _gemm_inputs(rows, n, k, dt, rows * 3 + n)
@@ -578,3 +578,36 @@ def test_ln_gemm_fused(gpu, dt, rows, n, epi):
     _lib.check(lib.vittf_gemm(_lib.ptr(hd), _lib.ptr(wd), _lib.ptr(biasd), _lib.ptr(out2), rows, n, 384, code, 0,
                               _lib.DTYPES[dt], _lib.stream_ptr()))
     assert rel_fro(got[:rows], out2.float().cpu().double()) <= EPS[dt] / 2
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows,k', [(256, 384), (1030, 1536), (33000, 384), (4097 * 3, 1536), (100, 384)])
+def test_gemm_residual_ln(gpu, dt, rows, k):
+    """x += a . w^T + bias and h = LayerNorm(x) in one call (whole-row GEMM with the LayerNorm in its epilogue + the tiled /
+    LayerNorm kernels for the rows beyond the last full 256-row tile) against fp64 and against the separate kernels."""
+    lib = _lib.load()
+    n = 384
+    a, w, bias, ref = _gemm_inputs(rows, n, k, dt, rows + k)
+    g = gen(rows)
+    x0 = torch.randn(rows + 2, n, generator=g) * 3.0
+    lg, lb = 1.0 + 0.2 * torch.randn(n, generator=g), 0.1 * torch.randn(n, generator=g)
+    ad, wd, bd, gd, ld = a.to(gpu), w.to(gpu), bias.to(gpu), lg.to(gpu), lb.to(gpu)
+    xd = x0.to(gpu)
+    hd = torch.full((rows + 2, n), 7.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_gemm_residual_ln(_lib.ptr(ad), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(xd), rows, n, k, _lib.DTYPES[dt],
+                                          _lib.ptr(gd), _lib.ptr(ld), 1e-6, _lib.ptr(hd), _lib.stream_ptr()))
+    gx, gh = xd.cpu().double(), hd.float().cpu().double()
+    assert torch.equal(gx[rows:], x0[rows:].double()) and (gh[rows:] == 7.0).all(), 'wrote past the last row'
+    xref = x0[:rows].double() + ref
+    assert ((gx[:rows] - xref).abs() <= 1e-5 * k ** 0.5 + 1e-6 * ref.abs()).all()
+    href = F.layer_norm(gx[:rows], (n,), lg.double(), lb.double(), 1e-6)           # LayerNorm of the x the kernel produced
+    assert ((gh[:rows] - href).abs() <= EPS[dt] * href.abs() * 1.01 + 2e-5).all()
+    # the separate kernels give the same bits for x and h
+    x2 = x0.to(gpu)
+    h2 = torch.empty(rows, n, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_gemm(_lib.ptr(ad), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(x2), rows, n, k, _lib.EPI_BIAS_RESIDUAL, 0,
+                              _lib.DTYPES[dt], _lib.stream_ptr()))
+    _lib.check(lib.vittf_layernorm(_lib.ptr(x2), _lib.ptr(gd), _lib.ptr(ld), _lib.ptr(h2), rows, n, 1e-6, _lib.DTYPES[dt],
+                                   _lib.stream_ptr()))
+    assert torch.equal(x2.cpu(), xd.cpu())
+    assert float((h2.float().cpu() - hd[:rows].float().cpu()).abs().max()) <= 2 * EPS[dt] * float(h2.float().abs().max())

@@ -56,6 +56,12 @@ def main():
             fl = 2 * rows * n * k
             byts = rows * k * 2 + n * k * 2 + rows * n * (8 if epi == 2 else 2)
             print(f'gemm {name:9s} [{rows}x{k}]x[{n}x{k}]^T: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s   {byts / ms / 1e6:.0f} GB/s algorithmic')
+            if epi == 2:   # the same GEMM with the following LayerNorm in its epilogue (16-bit h written as well)
+                lg = torch.ones(n, device=dev); lb = torch.zeros(n, device=dev)
+                h = torch.empty(rows, n, dtype=TDT[dt], device=dev)
+                ms = timeit(lambda: _lib.check(lib.vittf_gemm_residual_ln(_lib.ptr(a), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(o), rows, n, k, _lib.DTYPES[dt], _lib.ptr(lg), _lib.ptr(lb), 1e-6, _lib.ptr(h), _lib.stream_ptr())))
+                byts += rows * n * 2
+                print(f'gemm {name + "+ln":9s} [{rows}x{k}]x[{n}x{k}]^T: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s   {byts / ms / 1e6:.0f} GB/s algorithmic')
     if 'stock' in what:   # the same shapes on the stock ROCm libraries (hipBLASLt, SDPA): what unmodified torch would do here
         import torch.nn.functional as F
         for name, n, k in (('qkv', 3 * d, d), ('proj', d, d), ('fc1', 4 * d, d), ('fc2', d, 4 * d)):

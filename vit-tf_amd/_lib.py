@@ -64,6 +64,7 @@ SIGNATURES = {
     'vittf_patch_embed': (C.c_int, [_P(VitConfig), _P(VitWeights), _P(PosEmbed), _P(SliceView), _i32, _i32, _vp, _vp]),
     'vittf_layernorm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, C.c_float, _i32, _vp]),
     'vittf_gemm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'vittf_gemm_residual_ln': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp]),
     'vittf_ln_gemm': (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'vittf_mlp_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -124,9 +124,13 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   // 16-bit rows), which costs more than the LayerNorm launches: 1690 against 1720 slices/s on the 256^3 workload.
   static const bool ln_fused_env = [] { const char* e = getenv("VITTF_LN_FUSED"); return e && atoi(e) != 0; }();
   const bool ln_fused = ln_fused_env && d == 384 && !(w->fc2_w_perm);
+  // ViT-S default: every LayerNorm but the first rides on the epilogue of the residual GEMM in front of it
+  // (vittf_gemm_residual_ln: proj -> norm2, fc2 -> the next block's norm1); VITTF_RESIDUAL_LN=0 keeps them separate.
+  static const bool res_ln_env = [] { const char* e = getenv("VITTF_RESIDUAL_LN"); return !e || atoi(e) != 0; }();
+  const bool res_ln = res_ln_env && d == 384 && !ln_fused && !(w->fc2_w_perm);
   for (int l = 0; l < L; ++l) {
     const char* qkv_w = (const char*)w->qkv_w + (size_t)l * 3 * d * d * esz;
-    if (!ln_fused || l == L - 1) {
+    if (res_ln ? l == 0 : (!ln_fused || l == L - 1)) {
       ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
       rc = vittf_layernorm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
       if (rc) return rc;
@@ -154,10 +158,14 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
       rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, pre, stream); }
     if (rc) return rc;
     { ProfScope ps(VITTF_KERNEL_GEMM, stream);
-      rc = vittf_gemm(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d, d,
-                      VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
+      if (res_ln)
+        rc = vittf_gemm_residual_ln(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d,
+                                    d, dt, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, cfg->ln_eps, H, stream);
+      else
+        rc = vittf_gemm(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d, d,
+                        VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
     if (rc) return rc;
-    if (!ln_fused) {
+    if (!ln_fused && !res_ln) {
       ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
       rc = vittf_layernorm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
       if (rc) return rc;
@@ -179,8 +187,13 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
                           4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream); }
       if (rc) return rc;
       { ProfScope ps(VITTF_KERNEL_GEMM, stream);
-        rc = vittf_gemm(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
-                        4 * d, VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
+        if (res_ln)   // (l + 1 < L always holds here: the last block returns above)
+          rc = vittf_gemm_residual_ln(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows,
+                                      d, 4 * d, dt, w->ln1_g + (size_t)(l + 1) * d, w->ln1_b + (size_t)(l + 1) * d,
+                                      cfg->ln_eps, H, stream);
+        else
+          rc = vittf_gemm(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
+                          4 * d, VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
       if (rc) return rc;
     }
   }

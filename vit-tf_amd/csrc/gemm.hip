@@ -276,6 +276,9 @@ int launch_gemm(const void* a, const void* w, const float* bias, void* out, int6
 int vittf_gemm_ws(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
                   int32_t epilogue, int32_t dtype, hipStream_t st);   // gemm_ws.hip; 1 = not covered
 
+int vittf_gemm_rows(const void* a, const void* w, const float* bias, float* x, int64_t rows, int32_t n, int32_t k,
+                    int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h, hipStream_t st);   // gemm_rows.hip
+
 extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n,
                           int32_t k, int32_t epilogue, int32_t tokens, int32_t dtype, void* stream) {
   if (!a || !w || !bias || !out || rows <= 0 || n <= 0 || k <= 0) return VITTF_ERR_INVALID_ARG;
@@ -289,7 +292,34 @@ extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void*
     const int rc = vittf_gemm_ws(a, w, bias, out, rows, n, k, epilogue, dtype, st);
     if (rc != 1) return rc;
   }
+  // residual epilogue with 384 output columns (ViT-S proj / fc2): whole-row kernel for the full 256-row tiles, the tiled
+  // kernel below for the remaining rows (VITTF_GEMM_ROWS=0: tiled kernel only)
+  static const bool use_rows = [] { const char* e = getenv("VITTF_GEMM_ROWS"); return !e || atoi(e) != 0; }();
+  if (use_rows && epilogue == VITTF_EPI_BIAS_RESIDUAL && n == 384) {
+    const int rc = vittf_gemm_rows(a, w, bias, (float*)out, rows, n, k, dtype, nullptr, nullptr, 0.f, nullptr, st);
+    if (rc != 1) return rc;
+  }
   if (dtype == VITTF_BF16) return launch_gemm<VITTF_BF16>(a, w, bias, out, rows, n, k, epilogue, tokens, st);
   if (dtype == VITTF_FP16) return launch_gemm<VITTF_FP16>(a, w, bias, out, rows, n, k, epilogue, tokens, st);
   return VITTF_ERR_INVALID_ARG;
+}
+
+// x += a . w^T + bias (fp32 residual stream, n = 384), then h = LayerNorm(x; g, b) as the 16-bit operand of the next
+// GEMM: whole-row kernel with the LayerNorm in its epilogue; shapes it does not cover take the two separate kernels.
+extern "C" int vittf_layernorm(const float* x, const float* g, const float* b, void* y, int64_t rows, int32_t d, float eps,
+                               int32_t dtype, void* stream);
+extern "C" int vittf_gemm_residual_ln(const void* a, const void* w, const float* bias, float* x, int64_t rows, int32_t n,
+                                      int32_t k, int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h,
+                                      void* stream) {
+  if (!a || !w || !bias || !x || !ln_g || !ln_b || !h || rows <= 0 || n <= 0 || k <= 0) return VITTF_ERR_INVALID_ARG;
+  if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  static const bool use_rows = [] { const char* e = getenv("VITTF_GEMM_ROWS"); return !e || atoi(e) != 0; }();
+  if (use_rows && n == 384) {
+    const int rc = vittf_gemm_rows(a, w, bias, x, rows, n, k, dtype, ln_g, ln_b, ln_eps, h, st);
+    if (rc != 1) return rc;
+  }
+  const int rc = vittf_gemm(a, w, bias, x, rows, n, k, VITTF_EPI_BIAS_RESIDUAL, 0, dtype, stream);
+  if (rc != VITTF_OK) return rc;
+  return vittf_layernorm(x, ln_g, ln_b, h, rows, n, ln_eps, dtype, stream);
 }
