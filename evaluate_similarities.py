@@ -1,6 +1,6 @@
 """Drop-in for the reference's ``evaluate_similarities.py`` (:37-83): scores exported ``predictions.npy``
-against a label volume and writes ``metrics.json``.  Scoring only -- O(Nvox) CPU bookkeeping, no kernel
-(SURVEY.md 3.3); kept so the workflow around the hot path runs unchanged.  Works without icecream."""
+against a label volume and writes ``metrics.json``.  The confusion matrices are counted on the GPU
+(vittf_confusion_matrix); kept so the workflow around the hot path runs unchanged.  Works without icecream."""
 import json
 from argparse import ArgumentParser
 from pathlib import Path
@@ -10,27 +10,16 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+import vit_tf_amd as vt
+
 label2idx = {'background': 0, 'liver': 1, 'bladder': 2, 'lung': 3, 'kidney': 4, 'bone': 5}
 idx2label = ['liver', 'bladder', 'lung', 'kidney', 'bone']
 
 
 def binary_scores(target, pred):
-    """precision / recall / f1 / iou per class [0, 1], 2x2 confusion matrix, accuracy (:65-68)."""
-    try:
-        from sklearn.metrics import precision_recall_fscore_support, jaccard_score, confusion_matrix, accuracy_score
-        prec, rec, f1, _ = precision_recall_fscore_support(target, pred, average=None)
-        return (accuracy_score(target, pred), prec.tolist(), rec.tolist(), f1.tolist(),
-                jaccard_score(target, pred, average=None).tolist(), confusion_matrix(target, pred).tolist())
-    except ImportError:
-        t, p = np.asarray(target).astype(np.int64), np.asarray(pred).astype(np.int64)
-        k = int(max(t.max(), p.max())) + 1
-        cm = np.zeros((k, k), dtype=np.int64)
-        np.add.at(cm, (t, p), 1)
-        tp = np.diag(cm).astype(np.float64)
-        with np.errstate(divide='ignore', invalid='ignore'):
-            prec = np.nan_to_num(tp / cm.sum(0)); rec = np.nan_to_num(tp / cm.sum(1))
-            f1 = np.nan_to_num(2 * prec * rec / (prec + rec)); iou = np.nan_to_num(tp / (cm.sum(0) + cm.sum(1) - tp))
-        return float(tp.sum() / cm.sum()), prec.tolist(), rec.tolist(), f1.tolist(), iou.tolist(), cm.tolist()
+    """precision / recall / f1 / iou per class [0, 1], 2x2 confusion matrix, accuracy (:65-68); counted on the GPU."""
+    acc, prec, rec, f1, iou, cm = vt.scores.scores(target, pred)
+    return acc, prec.tolist(), rec.tolist(), f1.tolist(), iou.tolist(), cm.tolist()
 
 
 def evaluate(data_dir, label_fn, label_names):

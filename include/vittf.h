@@ -269,6 +269,26 @@ int vittf_topk_voxels(const float* maps, int32_t nmaps, int64_t nvox, int32_t k,
  * with eps 1e-8) or mean_j |x_i - x_j|_2 (measure 1, torch.cdist); x fp32 [n][f], dist fp32 [n]. */
 int vittf_mean_pairwise_distance(const float* x, int32_t n, int32_t f, int32_t measure, float* dist, void* stream);
 
+/* ---- label-volume helpers: sampler candidate masks and scores --------------------------- */
+/* dst = binary_erosion(set, generate_binary_structure(3, connectivity)) with scipy.ndimage's defaults (one iteration,
+ * border_value 0): set = {src == class_id} (class_id 0..255) or {src != 0} (class_id < 0); uint8 volumes (n0, n1, n2),
+ * dst 0/1, src != dst.  connectivity 1 = 6 face neighbours, 2 = 18, >= 3 = the full 3x3x3 cube. */
+int vittf_erode_mask(const uint8_t* src, int32_t n0, int32_t n1, int32_t n2, int32_t class_id, int32_t connectivity,
+                     uint8_t* dst, void* stream);
+
+/* sample_surface's candidate set (compare_feat_sampling.py:19-24): outer = erosion of {labels == class_id} by
+ * generate_binary_structure(3, connectivity = dist_from_surface), shell = outer XOR erosion of outer by the 6-neighbour
+ * element; shell uint8 0/1 (n0, n1, n2); ws: vittf_surface_shell_workspace_bytes(n0, n1, n2). */
+size_t vittf_surface_shell_workspace_bytes(int32_t n0, int32_t n1, int32_t n2);
+int vittf_surface_shell(const uint8_t* labels, int32_t n0, int32_t n1, int32_t n2, int32_t class_id, int32_t connectivity,
+                        uint8_t* shell, void* ws, size_t ws_bytes, void* stream);
+
+/* counts[t * classes + p] = number of voxels with target t and prediction p (sklearn confusion_matrix with labels
+ * 0..classes-1; predict_ntf.py:228-246, evaluate_similarities.py:63-68); counts[classes * classes] = voxels holding a
+ * value >= classes in either volume.  counts: int64 [classes * classes + 1] (device, overwritten); classes <= 16. */
+int vittf_confusion_matrix(const uint8_t* target, const uint8_t* pred, int64_t n, int32_t classes, int64_t* counts,
+                           void* stream);
+
 /* ---- 3-D bilateral solver post-process (bilateral_solver3d.py, predict_ntf.py:73-96) ---------- */
 typedef struct vittf_bilateral_params {
   double sigma_spatial;        /* grid_params['sigma_spatial'] (predict_ntf.py:75-79: 7) */

@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 
 import vit_tf_amd as vt
-from vit_tf_amd.samplers import sample_uniform, sample_surface, sample_both
+from vit_tf_amd.samplers import sample_uniform, sample_surface, sample_both, device_labels
 from infer import make_3d, make_4d, make_5d, sample_features3d, norm_minmax   # noqa: F401  (re-exported like the reference)
 
 sampling_modes = {
@@ -44,23 +44,8 @@ def assign_labels(similarities):
 
 
 def _metrics(labels, pred, names):
-    """(:228-246) sklearn when it is installed, the same quantities from a confusion matrix otherwise."""
-    y, p = labels.reshape(-1), pred.reshape(-1)
-    try:
-        from sklearn.metrics import precision_recall_fscore_support, jaccard_score, confusion_matrix, accuracy_score
-        prec, rec, f1, _ = precision_recall_fscore_support(y, p, average=None)
-        cm = confusion_matrix(y, p)
-        acc = accuracy_score(y, p)
-        iou = jaccard_score(y, p, average=None)
-    except ImportError:
-        k = int(max(y.max(), p.max())) + 1
-        cm = np.zeros((k, k), dtype=np.int64)
-        np.add.at(cm, (y.astype(np.int64), p.astype(np.int64)), 1)
-        tp = np.diag(cm).astype(np.float64)
-        with np.errstate(divide='ignore', invalid='ignore'):
-            prec = np.nan_to_num(tp / cm.sum(0)); rec = np.nan_to_num(tp / cm.sum(1))
-            f1 = np.nan_to_num(2 * prec * rec / (prec + rec)); iou = np.nan_to_num(tp / (cm.sum(0) + cm.sum(1) - tp))
-        acc = tp.sum() / cm.sum()
+    """(:228-246) accuracy, per-class precision / recall / F1 / IoU and the confusion matrix (counted on the GPU)."""
+    acc, prec, rec, f1, iou, cm = vt.scores.scores(labels, pred)
     return {
         'mAcc': float(acc),
         'precision': dict(zip(names, prec.tolist())), 'mPrec': float(prec.mean()),
@@ -111,12 +96,12 @@ def main(argv=None):
     elif args.num_samples > 0.0:
         draw = sampling_modes[args.sampling_mode]
         annotations = {}
+        labels_dev = device_labels(labels)                 # one upload; every class draws from it
         for i in range(1, int(labels.max()) + 1):
-            mask = torch.as_tensor(labels == i)
-            total = int(mask.sum().item())
+            total = int((labels_dev == i).sum().item())
             n = min(int(args.num_samples), total) if args.num_samples > 1.0 else int(args.num_samples * total)
             if n > 0:
-                annotations[f'ntf{i}'] = draw(mask, n, thin_to_reasonable=True)
+                annotations[f'ntf{i}'] = draw(labels_dev, n, thin_to_reasonable=True, class_id=i)
     else:
         raise Exception(f'Invalid value for --num-samples: {args.num_samples}')
 

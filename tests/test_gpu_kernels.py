@@ -611,3 +611,79 @@ def test_gemm_residual_ln(gpu, dt, rows, k):
                                    _lib.stream_ptr()))
     assert torch.equal(x2.cpu(), xd.cpu())
     assert float((h2.float().cpu() - hd[:rows].float().cpu()).abs().max()) <= 2 * EPS[dt] * float(h2.float().abs().max())
+
+
+@pytest.mark.parametrize('shape', [(32, 32, 32), (17, 70, 9), (5, 3, 130), (1, 1, 1), (3, 5, 16), (2, 70, 1024), (4, 1, 8)])
+@pytest.mark.parametrize('connectivity', [1, 2, 3, 4])
+def test_surface_shell_matches_scipy(gpu, shape, connectivity):
+    """vittf_erode_mask / vittf_surface_shell against scipy.ndimage.binary_erosion (the reference's own dependency,
+    compare_feat_sampling.py:19-24) bit for bit: blobs touching the border, ragged shapes, all structuring elements."""
+    from scipy.ndimage import binary_erosion, generate_binary_structure
+    from oracle import samplers as osmp
+    lib = _lib.load()
+    g = gen(sum(shape) + connectivity)
+    lab = (torch.rand(shape, generator=g) < 0.85).to(torch.uint8) * 3          # class 3, dense enough to survive two erosions
+    lab[torch.rand(shape, generator=g) < 0.03] = 1                              # another class sprinkled in
+    d = lab.to(gpu)
+    out = torch.full_like(d, 9)
+    _lib.check(lib.vittf_erode_mask(_lib.ptr(d), *shape, 3, connectivity, _lib.ptr(out), _lib.stream_ptr()))
+    ref = binary_erosion(lab.numpy() == 3, generate_binary_structure(3, connectivity))
+    assert np.array_equal(out.cpu().numpy().astype(bool), ref) and int(out.max()) <= 1
+    _lib.check(lib.vittf_erode_mask(_lib.ptr(d), *shape, -1, connectivity, _lib.ptr(out), _lib.stream_ptr()))
+    assert np.array_equal(out.cpu().numpy().astype(bool), binary_erosion(lab.numpy() != 0, generate_binary_structure(3, connectivity)))
+    shell = vt.samplers.surface_shell(d, connectivity, class_id=3)
+    assert np.array_equal(shell.cpu().numpy().astype(bool), osmp.surface_shell(lab.numpy() == 3, connectivity))
+    assert np.array_equal(vt.samplers.surface_shell(lab.numpy() == 3, connectivity).cpu().numpy().astype(bool),
+                          osmp.surface_shell(lab.numpy() == 3, connectivity))
+
+
+def test_samplers_draw_from_the_reference_candidate_sets(gpu):
+    """sample_uniform / sample_surface / sample_both (compare_feat_sampling.py:13-33): distinct voxels, all inside the
+    class mask / the scipy shell; fewer shell voxels than requested -> the whole shell in index order, like the reference."""
+    from oracle import samplers as osmp
+    _, lab = vt.synthetic_volume('sphere_filled', 48)
+    labels = (lab.to(torch.uint8) * 2)
+    shell = osmp.surface_shell(lab.numpy())
+    torch.manual_seed(0)
+    dl = vt.samplers.device_labels(labels)
+    u = vt.samplers.sample_uniform(dl, 50, thin_to_reasonable=True, class_id=2)
+    assert u.shape == (50, 3) and u.dtype == torch.int64 and not u.is_cuda
+    assert bool(lab[u[:, 0], u[:, 1], u[:, 2]].all()) and len({tuple(r) for r in u.tolist()}) == 50
+    s = vt.samplers.sample_surface(lab.numpy(), 40)
+    assert s.shape == (40, 3) and bool(shell[s[:, 0], s[:, 1], s[:, 2]].all()) and len({tuple(r) for r in s.tolist()}) == 40
+    everything = vt.samplers.sample_surface(dl, 10 ** 6, class_id=2)
+    assert torch.equal(everything, torch.as_tensor(shell).nonzero())
+    b = vt.samplers.sample_both(dl, 30, class_id=2)
+    assert b.shape == (30, 3) and bool(shell[b[15:, 0], b[15:, 1], b[15:, 2]].all())
+
+
+@pytest.mark.parametrize('n,classes', [(0, 2), (1, 2), (1000, 2), (16 * 4096 + 7, 6), (3 * 10 ** 6 + 5, 16)])
+def test_confusion_matrix_matches_numpy(gpu, n, classes):
+    """vittf_confusion_matrix against np.add.at (what sklearn's confusion_matrix counts; predict_ntf.py:228-246): exact
+    int64 counts, aligned and unaligned pointers, tails, out-of-range labels reported."""
+    lib = _lib.load()
+    g = gen(n + classes)
+    t = torch.randint(0, classes, (n + 1,), generator=g, dtype=torch.uint8)
+    p = torch.where(torch.rand(n + 1, generator=g) < 0.7, t, torch.randint(0, classes, (n + 1,), generator=g, dtype=torch.uint8))
+    for off in (0, 1):                                     # off = 1: pointers not 16-byte aligned
+        tt, pp = t[off:off + n], p[off:off + n]
+        ref = np.zeros((classes, classes), np.int64)
+        np.add.at(ref, (tt.numpy().astype(np.int64), pp.numpy().astype(np.int64)), 1)
+        td, pd = t.to(gpu)[off:off + n], p.to(gpu)[off:off + n]
+        counts = torch.full((classes * classes + 1,), -5, dtype=torch.int64, device=gpu)
+        _lib.check(lib.vittf_confusion_matrix(_lib.ptr(td), _lib.ptr(pd), n, classes, _lib.ptr(counts), _lib.stream_ptr()))
+        got = counts.cpu().numpy()
+        assert got[-1] == 0 and np.array_equal(got[:-1].reshape(classes, classes), ref)
+    if n >= 1000:
+        ref0 = np.zeros((classes, classes), np.int64)
+        np.add.at(ref0, (t[:n].numpy().astype(np.int64), p[:n].numpy().astype(np.int64)), 1)
+        assert np.array_equal(vt.scores.confusion_matrix(t[:n], p[:n], classes), ref0)
+        bad = t[:n].clone(); bad[n // 2] = classes
+        with pytest.raises(ValueError):
+            vt.scores.confusion_matrix(bad, p[:n], classes)
+        # derived scores = oracle's restatement of the sklearn figures (binary case of evaluate_similarities.py:65-68)
+        tb, pb = (t[:n] > 0).to(torch.uint8), (p[:n] > 1).to(torch.uint8)
+        acc, prec, rec, f1, iou, cm = vt.scores.scores(tb, pb)
+        want = osim.evaluate_predictions(pb.numpy(), tb.numpy())
+        assert acc == want['accuracy'] and prec.tolist() == want['precision'] and rec.tolist() == want['recall']
+        assert f1.tolist() == want['f1'] and iou.tolist() == want['iou'] and cm.tolist() == want['confusion_matrix']

@@ -308,3 +308,16 @@ def test_optional_paths_agree_with_default(gpu):
     oracle = dino_vit.build_vit(arch, sd)
     ref = ofv.feature_volume(vol, oracle, 8, 2, 'all', batch_size=8)
     assert rel_fro(fused, ref) <= TOL['bf16'][0] and rel_fro(base, ref) <= TOL['bf16'][0]
+
+
+def test_evaluate_similarities_entry(gpu, tmp_path):
+    """evaluate_similarities.py:37-83 on a tiny export: nearest-resized label mask against the prediction."""
+    import evaluate_similarities as ev
+    labels = np.zeros((8, 8, 8), np.uint8); labels[2:6, 2:6, 2:6] = 3
+    np.save(tmp_path / 'labels.npy', labels)
+    pred = np.zeros((4, 4, 4), np.uint8); pred[1:3, 1:3, 1:3] = 1
+    np.save(tmp_path / 'predictions.npy', {'ntf0': pred})
+    json.dump({'ntf0': {'time': 1.5, 'num_annotations': 3}}, open(tmp_path / 'metadata.json', 'w'))
+    res = ev.evaluate(tmp_path, tmp_path / 'labels.npy', ['lung'])
+    assert res['lung']['accuracy'] == 1.0 and res['lung']['iou'] == [1.0, 1.0] and res['lung']['num_annotations'] == 3
+    assert res['lung']['confusion_matrix'] == [[56, 0], [0, 8]]

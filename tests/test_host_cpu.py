@@ -160,24 +160,15 @@ def test_output_path_contract(tmp_path):
     assert np.load(tmp_path / 'f.npy', allow_pickle=True)[()]['k'].dtype == np.float16
 
 
-def test_evaluate_similarities_entry(tmp_path):
-    import json
-    import evaluate_similarities as ev
-    labels = np.zeros((8, 8, 8), np.uint8); labels[2:6, 2:6, 2:6] = 3
-    np.save(tmp_path / 'labels.npy', labels)
-    pred = np.zeros((4, 4, 4), np.uint8); pred[1:3, 1:3, 1:3] = 1
-    np.save(tmp_path / 'predictions.npy', {'ntf0': pred})
-    json.dump({'ntf0': {'time': 1.5, 'num_annotations': 3}}, open(tmp_path / 'metadata.json', 'w'))
-    res = ev.evaluate(tmp_path, tmp_path / 'labels.npy', ['lung'])
-    assert res['lung']['accuracy'] == 1.0 and res['lung']['iou'] == [1.0, 1.0] and res['lung']['num_annotations'] == 3
-
-
-def test_samplers():
-    from vit_tf_amd.samplers import sample_uniform, sample_surface, sample_both
+def test_sampler_oracle_is_the_scipy_restatement():
+    """oracle/samplers.py (CPU, scipy) draws distinct voxels of the mask / of its eroded shell."""
+    from oracle import samplers as osmp
     _, lab = vt.synthetic_volume('sphere_filled', 32)
     torch.manual_seed(0)
-    u = sample_uniform(lab, 20)
+    u = osmp.sample_uniform(lab, 20)
     assert u.shape == (20, 3) and bool(lab[u[:, 0], u[:, 1], u[:, 2]].all()) and len({tuple(r) for r in u.tolist()}) == 20
-    s = sample_surface(lab.numpy(), 20)
-    assert s.shape == (20, 3) and bool(lab[s[:, 0], s[:, 1], s[:, 2]].all())
-    assert sample_both(lab.numpy(), 10).shape == (10, 3)
+    shell = osmp.surface_shell(lab.numpy())
+    assert 0 < shell.sum() < lab.sum() and not (shell & ~lab.numpy().astype(bool)).any()
+    s = osmp.sample_surface(lab.numpy(), 20)
+    assert s.shape == (20, 3) and bool(shell[s[:, 0], s[:, 1], s[:, 2]].all())
+    assert osmp.sample_both(lab.numpy(), 10).shape == (10, 3)

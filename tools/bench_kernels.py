@@ -104,6 +104,23 @@ def main():
             err = (out.cpu() - ref).abs()
             print(f'  CPU restatement (numpy fp64, 1 process): {cpu_s:.1f} s; GPU vs CPU: median |diff| {float(err.median()):.2e}, '
                   f'voxels off by > 1e-3: {float((err > 1e-3).float().mean()):.2e}')
+    if 'labels' in what:   # sampler candidate masks + confusion matrix at the BASELINE configs[4] size (512^3 uint8 labels)
+        size = int(os.environ.get('LAB_SIZE', '512'))
+        _, lab = vt.ct_like_volume(size, seed=0)
+        dl = vt.samplers.device_labels(lab)
+        ms = timeit(lambda: vt.samplers.surface_shell(dl, 4, class_id=1), reps=5, warm=2)
+        print(f'surface shell {size}^3 (cube erosion + 6-neighbour erosion + xor): {ms:.3f} ms  {4 * dl.numel() / ms / 1e6:.0f} GB/s algorithmic (2 reads + 2 writes per voxel)')
+        pred = torch.where(torch.rand(dl.shape, device=dev) < 0.8, dl, torch.zeros_like(dl))
+        k = int(dl.max().item()) + 1
+        counts = torch.empty(k * k + 1, dtype=torch.int64, device=dev)
+        ms = timeit(lambda: _lib.check(lib.vittf_confusion_matrix(_lib.ptr(dl), _lib.ptr(pred), dl.numel(), k, _lib.ptr(counts), _lib.stream_ptr())), reps=5, warm=2)
+        print(f'confusion matrix {size}^3, {k} classes: {ms:.3f} ms  {2 * dl.numel() / ms / 1e6:.0f} GB/s')
+        if os.environ.get('LAB_CPU', '0') == '1':
+            import time
+            from oracle import samplers as osmp
+            t0 = time.perf_counter(); ref = osmp.surface_shell(lab.numpy() == 1); cpu_s = time.perf_counter() - t0
+            same = bool((vt.samplers.surface_shell(dl, 4, class_id=1).cpu().numpy().astype(bool) == ref).all())
+            print(f'  scipy binary_erosion x2 + xor on the host: {cpu_s:.1f} s; identical: {same}')
     if 'mlp' in what:
         hh = torch.randn(rows, d, generator=g).to(TDT[dt]).to(dev)
         w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(dev)

@@ -9,7 +9,7 @@ from .engine import HipViT                                          # noqa: F401
 from .extract import (sizing, feature_volume, pooled_axis, k_slices, DeviceVolume, AXIS_DIMS)     # noqa: F401
 from .similarity import sample_features3d, compute_similarities, assign_labels                    # noqa: F401
 from .synthetic import synthetic_volume, ct_like_volume, shapes                                   # noqa: F401
-from . import bilateral, similarity, weights                         # noqa: F401
+from . import bilateral, samplers, scores, similarity, weights                         # noqa: F401
 
 __all__ = ['HipViT', 'feature_volume', 'compute_similarities', 'sample_features3d', 'assign_labels',
            'synthetic_state_dict', 'sizing', 'VittfError']

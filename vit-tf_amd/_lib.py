@@ -80,6 +80,10 @@ SIGNATURES = {
                                             _vp, _sz, _vp]),
     'vittf_topk_voxels': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp]),
     'vittf_mean_pairwise_distance': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    'vittf_erode_mask': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'vittf_surface_shell_workspace_bytes': (_sz, [_i32, _i32, _i32]),
+    'vittf_surface_shell': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    'vittf_confusion_matrix': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     'vittf_bilateral_workspace_bytes': (_sz, [_i32, _i32, _i32, C.c_double, _i32]),
     'vittf_bilateral_refine': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _P(_i32), _i32,
                                          _P(BilateralParams), _vp, _P(_i32), _vp, _sz, _vp]),
