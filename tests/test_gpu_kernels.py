@@ -580,9 +580,16 @@ def test_ln_gemm_fused(gpu, dt, rows, n, epi):
     assert rel_fro(got[:rows], out2.float().cpu().double()) <= EPS[dt] / 2
 
 
+@pytest.fixture(params=['1', '2'])
+def rows_wm(request, monkeypatch):
+    """both workgroup shapes of the whole-row GEMM: 128 rows x 2 per CU (default) and 256 rows x 1 per CU"""
+    monkeypatch.setenv('VITTF_ROWS_WM', request.param)
+    return request.param
+
+
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('rows,k', [(256, 384), (1030, 1536), (33000, 384), (4097 * 3, 1536), (100, 384)])
-def test_gemm_residual_ln(gpu, dt, rows, k):
+def test_gemm_residual_ln(gpu, dt, rows, k, rows_wm):
     """x += a . w^T + bias and h = LayerNorm(x) in one call (whole-row GEMM with the LayerNorm in its epilogue + the tiled /
     LayerNorm kernels for the rows beyond the last full 256-row tile) against fp64 and against the separate kernels."""
     lib = _lib.load()

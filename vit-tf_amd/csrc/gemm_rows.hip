@@ -3,55 +3,75 @@
 // and, optionally in the same pass, the next LayerNorm:  h[rows][384] (16 bit) = LayerNorm(x_new; g, b).
 //
 // Why next to gemm.hip: a 128 x 128 tile moves 32 KB of operands from L2 into LDS per 64-wide K step, 2.36 GB per fc2
-// launch, and its run time follows L2->LDS bytes / ~17 TB/s + HBM bytes / ~5 TB/s.  Here a workgroup owns 256 whole
-// rows: 16 KB (activations) + 24 KB (all 384 weight rows) per 32-wide K step for 256 x 384 outputs = 0.98 GB per
-// launch (-58 %), and because the rows are whole the LayerNorm that follows every residual add can be computed on
-// the way out instead of by a separate kernel that re-reads the 201 MB stream.
+// launch, and its run time follows L2->LDS bytes / ~17 TB/s + HBM bytes / ~5 TB/s.  Here a workgroup owns whole rows:
+// 8 KB (activations) + 24 KB (all 384 weight rows) per 32-wide K step for 128 x 384 outputs = 1.57 GB per launch
+// (0.98 GB with 256-row workgroups), and because the rows are whole the LayerNorm that follows every residual add can
+// be computed on the way out instead of by a separate kernel that re-reads the 201 MB stream.
 //
-//   * 8 waves (2 per SIMD, 256 VGPRs) as 2 (rows) x 4 (columns): a wave owns 128 x 96 outputs = 12 accumulator tiles
-//     (192 VGPRs), computed transposed (weights = MFMA A operand, activations = B operand) like the other GEMMs;
-//     per 16-wide K slice 4 + 3 fragment reads feed 12 MFMAs.
-//   * operands arrive by LDS-DMA (asm pieces) into a 3-deep ring of 40 KB stages, one bare barrier per K step; a
-//     [R][32] operand image is stored as R / 2 "double rows" of 128 B in the tile_off() layout (rows 2 j and 2 j + 1
-//     side by side), which keeps the 16-byte fragment reads conflict-free.
-//   * epilogue in four rounds of 64 rows through a padded fp32 LDS tile (it reuses the ring), each round in two
-//     passes of 32 rows: 16 lanes per row do the read-modify-write as 256-byte runs with the x of the next pass
+//   * a wave owns 128 x 96 outputs = 12 accumulator tiles (192 VGPRs; 2 waves per SIMD), computed transposed (weights =
+//     MFMA A operand, activations = B operand) like the other GEMMs; per 16-wide K slice 4 + 3 fragment reads feed 12
+//     MFMAs.  Default (VITTF_ROWS_WM=1): workgroup = 4 waves side by side = 128 rows x 384 columns, 2-deep ring of
+//     32 KB stages, two workgroups per CU (each covers the other's DMA latency; finer tiles at the launch's tail);
+//     VITTF_ROWS_WM=2: 8 waves as 2 (rows) x 4 (columns) = 256 rows, 3-deep ring of 40 KB stages, one workgroup per
+//     CU (half the weight re-reads; same speed in isolation, 1 % slower in the pipeline).
+//   * operands arrive by LDS-DMA (asm pieces), one bare barrier per 32-wide K step; a [R][32] operand image is stored
+//     as R / 2 "double rows" of 128 B in the tile_off() layout (rows 2 j and 2 j + 1 side by side), which keeps the
+//     16-byte fragment reads conflict-free.
+//   * epilogue in four rounds of 32 rows per row half through a padded fp32 LDS tile (it reuses the ring), each round
+//     in two passes: 16 lanes per row do the read-modify-write as 256-byte runs with the x of the next pass
 //     already in flight, and -- with the whole row in those 16 lanes' registers -- the LayerNorm statistics,
 //     affine transform and 16-bit store.
 //   * a partial last tile reads zeros for its missing rows and drops their outputs, so a row's bits do not depend on
 //     where it sits in a launch (1 rank and N ranks batch the slices differently and must write the same file).
+//   * -DROWS_ABL_NO_MFMA / -DROWS_ABL_NO_EPI build timing-only variants (wrong results) that separate the memory side
+//     from the K loop: fc2 + LayerNorm 0.235 ms without MFMAs, 0.19 ms without the epilogue, 0.30 ms complete.
 #include "vittf_common.h"
+
+#include <stdlib.h>
 
 namespace {
 
-constexpr int RN = 384, RBM = 256, RBK = 32, RTHREADS = 512;
-constexpr int RA_BYTES = RBM * RBK * 2;           // 16 KB
+constexpr int RN = 384, RBK = 32;
 constexpr int RW_BYTES = RN * RBK * 2;            // 24 KB
-constexpr int RSTAGE = RA_BYTES + RW_BYTES;       // 40 KB
-constexpr int RSTAGES = 3;
 constexpr int RCS = RN * 4 + 16;                  // fp32 staging row stride
-constexpr int RBIAS_OFF = 64 * RCS;               // bias copy behind the 64-row staging tile (99,328 B)
-constexpr int RLDS = RSTAGES * RSTAGE;            // 122,880 B
-static_assert(RBIAS_OFF + 3 * RN * 4 <= RLDS, "staging tile + bias / gamma / beta must fit in the ring");
+
+// WM = row halves per workgroup: 2 -> 256 rows, 8 waves, 3-deep ring, one workgroup per CU;
+//                                1 -> 128 rows, 4 waves, 2-deep ring, two workgroups per CU (the epilogue of one
+//                                     overlaps the K loop of the other; the weight image is staged twice as often)
+template <int WM>
+struct RowsCfg {
+  static constexpr int BM = 128 * WM, THREADS = 256 * WM;
+  static constexpr int A_BYTES = BM * RBK * 2;                // 16 / 8 KB
+  static constexpr int STAGE = A_BYTES + RW_BYTES;            // 40 / 32 KB
+  static constexpr int STAGES = WM == 2 ? 3 : 2;
+  static constexpr int LDS = STAGES * STAGE;                  // 122,880 / 65,536 B
+  static constexpr int BIAS_OFF = 32 * WM * RCS;              // bias / gamma / beta behind the staging tile
+  static constexpr int W_PIECES = RW_BYTES / (THREADS * 16);  // 3 / 6 per thread and stage (+ 2 of the activation image)
+  static_assert(BIAS_OFF + 3 * RN * 4 <= LDS, "staging tile + bias / gamma / beta must fit in the ring");
+};
 
 #define ROWS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // byte offset of 16-byte k-chunk kc (0..3) of row r inside a [R][32] operand image
 __device__ __forceinline__ int img_off(int r, int kc) { return tile_off(r >> 1, ((r & 1) << 2) | kc); }
 
-template <int DT, bool LN>
-__global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_rows_kernel(
+template <int DT, bool LN, int WM>
+__global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_rows_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ X, int64_t rows, int k, const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
     unsigned short* __restrict__ H) {
-  __shared__ __attribute__((aligned(16))) char smem[RLDS];
+  using C = RowsCfg<WM>;
+  constexpr int RBM = C::BM, RTHREADS = C::THREADS, RA_BYTES = C::A_BYTES, RSTAGE = C::STAGE, RSTAGES = C::STAGES;
+  constexpr int RBIAS_OFF = C::BIAS_OFF;
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = WM == 2 ? wave >> 2 : 0, wn = wave & 3;
   const int64_t m0 = (int64_t)blockIdx.x * RBM;
 
-  // ---- LDS-DMA: 5 pieces per thread and stage (2 of the activation image, 3 of the weight image) ----
+  // ---- LDS-DMA pieces per thread and stage: 2 of the activation image, 3 / 6 of the weight image (pieces 3..5 of the
+  //      128-row variant are pieces 0..2 shifted by 192 weight rows: same lane offset, + 192 k 2 in the scalar offset)
   int voff[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
@@ -67,15 +87,22 @@ __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   const i32x4_t rsrc_w = lds_dma_rsrc(W, (unsigned)(RN * k * 2));
   const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(smem);
   const unsigned dma_wave = ring_lds + wave * 1024;
+  constexpr int PIECE = RTHREADS * 16;             // LDS bytes one piece of all threads covers (8 / 4 KB)
+  const int w_half = 192 * k * 2;
 #define ROWS_STAGE(T, BUF)                                                                      \
   {                                                                                             \
     const unsigned dst_ = dma_wave + (BUF) * RSTAGE;                                            \
     const int so_ = (T) * (RBK * 2);                                                            \
     lds_dma16(rsrc_a, dst_, voff[0], so_);                                                      \
-    lds_dma16(rsrc_a, dst_ + 8192, voff[1], so_);                                               \
+    lds_dma16(rsrc_a, dst_ + PIECE, voff[1], so_);                                              \
     lds_dma16(rsrc_w, dst_ + RA_BYTES, voff[2], so_);                                           \
-    lds_dma16(rsrc_w, dst_ + RA_BYTES + 8192, voff[3], so_);                                    \
-    lds_dma16(rsrc_w, dst_ + RA_BYTES + 16384, voff[4], so_);                                   \
+    lds_dma16(rsrc_w, dst_ + RA_BYTES + PIECE, voff[3], so_);                                   \
+    lds_dma16(rsrc_w, dst_ + RA_BYTES + 2 * PIECE, voff[4], so_);                               \
+    if (WM == 1) {                                                                              \
+      lds_dma16(rsrc_w, dst_ + RA_BYTES + 3 * PIECE, voff[2], so_ + w_half);                    \
+      lds_dma16(rsrc_w, dst_ + RA_BYTES + 4 * PIECE, voff[3], so_ + w_half);                    \
+      lds_dma16(rsrc_w, dst_ + RA_BYTES + 5 * PIECE, voff[4], so_ + w_half);                    \
+    }                                                                                           \
   }
 
   // ---- fragment addresses: block b (32 rows further) = + 2048 B and the swizzle bit flips when b is odd ----
@@ -96,14 +123,17 @@ __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   const int nk = k / RBK;
   ROWS_STAGE(0, 0)
-  if (nk > 1) ROWS_STAGE(1, 1)
+  if (RSTAGES == 3 && nk > 1) ROWS_STAGE(1, 1)
   for (int t = 0; t < nk; ++t) {
-    // this wave's pieces of stage t have landed (the 5 youngest may belong to stage t + 1)
-    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    // this wave's pieces of stage t have landed (3-deep ring: the 5 youngest may belong to stage t + 1)
+    if (RSTAGES == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ROWS_BARRIER();   // everybody's pieces have; and everybody is done with stage t - 1, whose buffer is refilled now
-    if (t + 2 < nk) ROWS_STAGE(t + 2, (t + 2) % RSTAGES)
+    if (t + RSTAGES - 1 < nk) ROWS_STAGE(t + RSTAGES - 1, (t + RSTAGES - 1) % RSTAGES)
     const char* buf = smem + (t % RSTAGES) * RSTAGE;
+#ifdef ROWS_ABL_NO_MFMA   // timing only
+    if (k > 0) continue;
+#endif
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       s16x8_t af[4], wf[3];
@@ -121,12 +151,18 @@ __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 #undef ROWS_STAGE
 
+#ifdef ROWS_ABL_NO_EPI   // timing only
+  if (ln_eps != 123.f) {
+    if (acc[0][0][0] + acc[1][1][1] + acc[2][2][2] + acc[0][3][3] + acc[1][2][5] + acc[2][1][7] == 1.2345f) X[tid] = 1.f;
+    return;
+  }
+#endif
   // ---- epilogue: four rounds of 64 rows (row block mb of both row halves) through a padded fp32 LDS tile ----
   ROWS_BARRIER();                                  // the last stage has been read by everybody: the ring is free
   float* const sbias = reinterpret_cast<float*>(smem + RBIAS_OFF);
   for (int i = tid; i < (LN ? 3 : 1) * RN; i += RTHREADS)
     sbias[i] = i < RN ? bias[i] : (i < 2 * RN ? ln_g[i - RN] : ln_b[i - 2 * RN]);
-  // read-modify-write in passes of 32 rows (one row half of the round): 16 lanes per row, 16-byte chunks seg + 16 j.
+  // read-modify-write in two passes per round (32 / 16 rows each): 16 lanes per row, 16-byte chunks seg + 16 j.
   // The x loads of the NEXT pass are issued before the stores of this one: the memory counter retires in issue order,
   // so a load waited for behind earlier stores would also wait for those stores.
   int tid_e = tid;
@@ -135,7 +171,8 @@ __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   float4 xn[6];
 #define ROWS_LOADX(MB, P)                                                                       \
   {                                                                                             \
-    const int rl_ = (P) * 128 + 32 * (MB) + row_p;                                              \
+    const int sr_ = (P) * (RTHREADS / 16) + row_p;                                              \
+    const int rl_ = (sr_ >> 5) * 128 + 32 * (MB) + (sr_ & 31);                                  \
     const float* xr_ = X + (m0 + (rl_ < rows_here ? rl_ : rows_here - 1)) * RN + seg * 4;       \
     _Pragma("unroll") for (int j = 0; j < 6; ++j) xn[j] = *reinterpret_cast<const float4*>(xr_ + 64 * j); \
   }
@@ -161,9 +198,11 @@ __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     ROWS_BARRIER();
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const int64_t gm = m0 + p * 128 + 32 * mb + row_p;
-      const bool live = p * 128 + 32 * mb + row_p < rows_here;
-      const char* sr = smem + (32 * p + row_p) * RCS + seg * 16;
+      const int srow = p * (RTHREADS / 16) + row_p;                 // row of the staging tile
+      const int rl = (srow >> 5) * 128 + 32 * mb + (srow & 31);     // row of the workgroup's tile
+      const int64_t gm = m0 + rl;
+      const bool live = rl < rows_here;
+      const char* sr = smem + srow * RCS + seg * 16;
       float4 x[6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) x[j] = xn[j];
@@ -215,19 +254,26 @@ __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
 int vittf_gemm_rows(const void* a, const void* w, const float* bias, float* x, int64_t rows, int32_t n, int32_t k,
                     int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h, hipStream_t st) {
   if (n != RN || k % RBK != 0 || k < 2 * RBK || rows <= 0) return 1;
-  if ((int64_t)RBM * k * 2 > 0x7fffffff || rows / RBM + 1 > 0x7fffffff) return 1;
-  const dim3 grid((unsigned)((rows + RBM - 1) / RBM)), block(RTHREADS);
+  if ((int64_t)256 * k * 2 > 0x7fffffff || rows / 128 + 1 > 0x7fffffff) return 1;
+  if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
+  const char* wm_env = getenv("VITTF_ROWS_WM");          // (read per call: the tests switch it)
+  const int wm = wm_env && atoi(wm_env) == 2 ? 2 : 1;
   const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Wp = (const unsigned short*)w;
   const bool ln = ln_g && ln_b && h;
+  const int bm = 128 * wm;
+  const dim3 grid((unsigned)((rows + bm - 1) / bm)), block(256 * wm);
+#define ROWS_LAUNCH(DT, LN, WM)                                                                                     \
+  hipLaunchKernelGGL((gemm_rows_kernel<DT, LN, WM>), grid, block, 0, st, A, Wp, bias, x, rows, k, ln_g, ln_b, ln_eps, \
+                     (unsigned short*)h)
+#define ROWS_LAUNCH_WM(DT, LN) \
+  { if (wm == 2) ROWS_LAUNCH(DT, LN, 2); else ROWS_LAUNCH(DT, LN, 1); }
   if (dtype == VITTF_BF16) {
-    if (ln) hipLaunchKernelGGL((gemm_rows_kernel<VITTF_BF16, true>), grid, block, 0, st, A, Wp, bias, x, rows, k, ln_g, ln_b, ln_eps, (unsigned short*)h);
-    else hipLaunchKernelGGL((gemm_rows_kernel<VITTF_BF16, false>), grid, block, 0, st, A, Wp, bias, x, rows, k, ln_g, ln_b, ln_eps, (unsigned short*)h);
-  } else if (dtype == VITTF_FP16) {
-    if (ln) hipLaunchKernelGGL((gemm_rows_kernel<VITTF_FP16, true>), grid, block, 0, st, A, Wp, bias, x, rows, k, ln_g, ln_b, ln_eps, (unsigned short*)h);
-    else hipLaunchKernelGGL((gemm_rows_kernel<VITTF_FP16, false>), grid, block, 0, st, A, Wp, bias, x, rows, k, ln_g, ln_b, ln_eps, (unsigned short*)h);
+    if (ln) ROWS_LAUNCH_WM(VITTF_BF16, true) else ROWS_LAUNCH_WM(VITTF_BF16, false)
   } else {
-    return VITTF_ERR_INVALID_ARG;
+    if (ln) ROWS_LAUNCH_WM(VITTF_FP16, true) else ROWS_LAUNCH_WM(VITTF_FP16, false)
   }
+#undef ROWS_LAUNCH_WM
+#undef ROWS_LAUNCH
   return vittf_check_launch();
 }
