@@ -351,7 +351,14 @@ def test_sample_features_golden(gpu, golden_dir):
             assert torch.allclose(got[0, 0].cpu(), ref, rtol=0, atol=1e-6)
 
 
-def test_similarity_golden(gpu, golden_dir):
+@pytest.fixture(params=['1', '0'])
+def sim_split(request, monkeypatch):
+    """both few-query similarity kernels: feature axis split over the workgroup's waves (default) / one thread per voxel pair"""
+    monkeypatch.setenv('VITTF_SIM_SPLIT', request.param)
+    return request.param
+
+
+def test_similarity_golden(gpu, golden_dir, sim_split):
     g = load_golden(golden_dir, 'similarity.npz')
     feat = torch.from_numpy(g['feat'])
     vol = np.zeros(tuple(int(x) for x in g['vol_shape']), dtype=np.float32)
@@ -367,7 +374,7 @@ def test_similarity_golden(gpu, golden_dir):
     assert (diff != 0).sum() <= 2 and np.abs(diff[np.abs(diff) < 128]).max(initial=0) <= 1
 
 
-def test_similarity_many_classes_and_chunks(gpu):
+def test_similarity_many_classes_and_chunks(gpu, sim_split):
     """17 + 16 + 1 + 40 annotations in 4 classes: chunks of 16 straddle class boundaries; vs the oracle."""
     g = gen(21)
     feat = F.normalize(torch.randn(64, 6, 7, 8, generator=g), dim=0)
@@ -385,6 +392,35 @@ def test_similarity_many_classes_and_chunks(gpu):
     assert np.array_equal(labels, osim.assign_labels([got[k] for k in ann]))     # bit-exact on the same maps
 
 
+def test_similarity_split_kernel_matches_plain_kernel(gpu, monkeypatch):
+    """fp32 class maps of the two few-query kernels on a 32^3 x 384 volume, 3 classes / 21 annotations (two chunks):
+    same values up to the summation order of the dot products."""
+    lib = _lib.load()
+    g = gen(77)
+    f, n = 384, 32
+    feat = F.normalize(torch.randn(f, n, n, n, generator=g), dim=0).half().to(gpu)
+    qf = (feat.float().reshape(f, -1)[:, torch.randint(0, n ** 3, (21,), generator=g).to(gpu)].T
+          + 0.02 * torch.randn(21, f, generator=g).to(gpu)).contiguous()      # queries near voxels of the volume
+    starts = np.array([0, 5, 6, 21], np.int32)
+    ws_bytes = lib.vittf_similarity_workspace_bytes(3, 0, 21)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=gpu)
+    maps = {}
+    for split in ('1', '0'):
+        monkeypatch.setenv('VITTF_SIM_SPLIT', split)
+        out = torch.full((3 * n ** 3 + 1,), 7.0, device=gpu)
+        _lib.check(lib.vittf_similarity_maps_f32(_lib.ptr(feat), 1, f, n, n, n, _lib.ptr(qf), starts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                 3, 0, 0.0, None, _lib.ptr(out), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()))
+        assert float(out[-1]) == 7.0, 'wrote past the last map'
+        maps[split] = out[:-1].cpu().view(3, -1)
+    assert float(maps['1'].max()) > 0.01
+    assert torch.allclose(maps['1'], maps['0'], rtol=2e-5, atol=1e-7)
+    dots = torch.einsum('fv,af->av', feat.float().cpu().reshape(f, -1).double(), qf.cpu().double())
+    act = torch.where(dots >= 0.25, dots, torch.zeros_like(dots)) ** 2.5
+    ref = torch.stack([act[a:b].mean(0) for a, b in zip(starts[:-1], starts[1:])])
+    edge = ((dots - 0.25).abs() < 1e-5).any(0)                      # the threshold decides differently in fp32 / fp64 there
+    assert torch.allclose(maps['1'].double()[:, ~edge], ref[:, ~edge], rtol=1e-4, atol=1e-7)
+
+
 def test_labels_bit_exact_random(gpu):
     g = gen(8)
     sims = [torch.randint(0, 256, (9, 10, 11), generator=g, dtype=torch.uint8) for _ in range(5)]
@@ -393,7 +429,7 @@ def test_labels_bit_exact_random(gpu):
     assert np.array_equal(vt.assign_labels(sims7), osim.assign_labels(sims7))
 
 
-def test_cosine_similarity_option(gpu):
+def test_cosine_similarity_option(gpu, sim_split):
     """normalize=True: per-voxel L2 normalisation of the volume (F.normalize(feat, dim=0)) folded into the sampling and
     similarity kernels through a norm array, against the oracle that normalises the volume explicitly."""
     g = gen(33)

@@ -133,6 +133,58 @@ __device__ __forceinline__ float activate(float s, float expo) {
   return c > 0.f ? __builtin_amdgcn_exp2f(expo * __builtin_amdgcn_logf(c)) : 0.f;   // v_log_f32 is log2
 }
 
+// Everything after the dot products, for the NV voxels v0.. of one thread: cosine normalisation, per-class reduction over
+// the chunk's annotations, accumulate / finalise the class maps, per-class maximum.
+template <bool BIG, int ACT, int NV>
+__device__ __forceinline__ void sim_finish(float (&acc)[ACH][NV], int64_t v0, int64_t nvox, const SimChunk& ch,
+                                           const float* __restrict__ vnorm, float expo, float* __restrict__ sim,
+                                           unsigned* __restrict__ maxbits) {
+  if (vnorm) {     // cosine similarity: the volume is normalised per voxel (the queries were sampled from it normalised)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const float nv = (v0 + j < nvox) ? vnorm[v0 + j] : 1.f;
+#pragma unroll
+      for (int a = 0; a < ACH; ++a) acc[a][j] = acc[a][j] / nv;
+    }
+  }
+  // per-class reduction over the chunk's annotations: they are sorted by class, so a running sum in annotation order is
+  // handed over whenever the next annotation belongs to another class (wave-uniform branches: the activation is
+  // evaluated once per value and at most nc hand-overs run)
+  float run[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) run[j] = 0.f;
+#pragma unroll
+  for (int a = 0; a < ACH; ++a) {      // (fully unrolled: acc must keep static indices; padding queries are zero and add 0)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) run[j] += BIG ? acc[a][j] : activate<ACT>(acc[a][j], expo);
+    const bool hand_over = a < ch.n_ann && (a + 1 == ch.n_ann || (a + 1 < ACH && ch.cls[a + 1 < ACH ? a + 1 : a] != ch.cls[a]));
+    if (hand_over) {                   // wave-uniform
+      const int c = ch.cls[a];
+      float* dst = sim + (int64_t)(ch.c0 + c) * nvox + v0;
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        if (v0 + j < nvox) {
+          float t = run[j];
+          if (!ch.first[c]) t += dst[j];
+          if (ch.last[c]) {
+            t = t / ch.count[c];                // mean = sum / count (predict_ntf.py:72 / :63), true division
+            if (BIG) t = activate<ACT>(t, expo);
+            m = fmaxf(m, t);
+          }
+          dst[j] = t;
+        }
+        run[j] = 0.f;
+      }
+      if (ch.last[c]) {   // sims are >= 0, so the uint bit pattern orders like the float: one atomicMax per wave and class
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxbits + ch.c0 + c, __float_as_uint(m));
+      }
+    }
+  }
+}
+
 template <bool BIG, int ACT, bool HALF>
 __global__ __launch_bounds__(256) void sim_accumulate(const void* __restrict__ feat_v, int f, int64_t nvox,
                                                       const float* __restrict__ qf_t, SimChunk ch,
@@ -173,55 +225,70 @@ __global__ __launch_bounds__(256) void sim_accumulate(const void* __restrict__ f
       }
     }
   }
-  if (vnorm) {     // cosine similarity: the volume is normalised per voxel (the queries were sampled from it normalised)
+  sim_finish<BIG, ACT, VPT>(acc, v0, nvox, ch, vnorm, expo, sim, maxbits);
+}
+
+// The same pass with the feature axis split over the workgroup's four waves (f % 4 == 0, nvox % 4 == 0): a 64^3 volume
+// has only 2 waves per SIMD worth of voxels at 2 voxels per thread, too few loads in flight for the 201 MB stream
+// (181 us = 1.1 TB/s).  Here a thread takes 4 voxels (8- / 16-byte loads) of one quarter of the features, so four times as many
+// independent load streams are in flight; the partial dot products meet in wave 0 through LDS as (p0 + p2) + (p1 + p3),
+// and wave 0 finishes as above: 56-62 us = 3.5 TB/s.
+constexpr int SVPT = 4;
+template <bool BIG, int ACT, bool HALF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void sim_accumulate_split(
+    const void* __restrict__ feat_v, int f, int64_t nvox, const float* __restrict__ qf_t, SimChunk ch,
+    const float* __restrict__ vnorm, float expo, float* __restrict__ sim, unsigned* __restrict__ maxbits) {
+  __shared__ float part[2][ACH * SVPT][64];                 // 32 KB: [slot][annotation * 4 + voxel][lane]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t v0 = ((int64_t)blockIdx.x * 64 + lane) * SVPT;
+  float acc[ACH][SVPT];
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-      const float nv = (v0 + j < nvox) ? vnorm[v0 + j] : 1.f;
+  for (int a = 0; a < ACH; ++a)
 #pragma unroll
-      for (int a = 0; a < ACH; ++a) acc[a][j] = acc[a][j] / nv;
-    }
-  }
-  // per-class reduction over the chunk's annotations
-  float blockmax[MAXC];
+    for (int j = 0; j < SVPT; ++j) acc[a][j] = 0.f;
+  const int fq = f >> 2, f0 = wave * fq;
+  if (v0 < nvox) {                                            // (nvox % 4 == 0: all four voxels exist)
+#pragma unroll 8
+    for (int ff = f0; ff < f0 + fq; ++ff) {
+      float x[SVPT];
+      if constexpr (HALF) {
+        const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(feat_v) + (int64_t)ff * nvox + v0);
+        x[0] = f16bits_to_f32((unsigned short)(raw.x & 0xffff)); x[1] = f16bits_to_f32((unsigned short)(raw.x >> 16));
+        x[2] = f16bits_to_f32((unsigned short)(raw.y & 0xffff)); x[3] = f16bits_to_f32((unsigned short)(raw.y >> 16));
+      } else {
+        const float4 raw = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(feat_v) + (int64_t)ff * nvox + v0);
+        x[0] = raw.x; x[1] = raw.y; x[2] = raw.z; x[3] = raw.w;
+      }
+      const float* q = qf_t + ff * ACH;   // wave-uniform -> scalar loads
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    blockmax[c] = 0.f;
-    if (c < ch.nc) {
-      float cs[VPT];
+      for (int a = 0; a < ACH; ++a) {
+        const float qa = q[a];
 #pragma unroll
-      for (int j = 0; j < VPT; ++j) cs[j] = 0.f;
-#pragma unroll
-      for (int a = 0; a < ACH; ++a)
-        if (a < ch.n_ann && ch.cls[a] == c) {
-#pragma unroll
-          for (int j = 0; j < VPT; ++j) cs[j] += BIG ? acc[a][j] : activate<ACT>(acc[a][j], expo);
-        }
-      float* dst = sim + (int64_t)(ch.c0 + c) * nvox + v0;
-#pragma unroll
-      for (int j = 0; j < VPT; ++j) {
-        if (v0 + j < nvox) {
-          float t = cs[j];
-          if (!ch.first[c]) t += dst[j];
-          if (ch.last[c]) {
-            t = t / ch.count[c];                // mean = sum / count (predict_ntf.py:72 / :63), true division
-            if (BIG) t = activate<ACT>(t, expo);
-            blockmax[c] = fmaxf(blockmax[c], t);
-          }
-          dst[j] = t;
-        }
+        for (int j = 0; j < SVPT; ++j) acc[a][j] = fmaf(x[j], qa, acc[a][j]);
       }
     }
   }
-  // sims are >= 0, so the uint bit pattern orders like the float: one atomicMax per wave per finished class
-#pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    if (c < ch.nc && ch.last[c]) {
-      float m = blockmax[c];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-      if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxbits + ch.c0 + c, __float_as_uint(m));
-    }
-  }
+  // (p0 + p2) + (p1 + p3) in two steps through a 32 KB buffer, 128 VGPRs: four workgroups per CU, so the 1024
+  // workgroups of a 64^3 volume are resident at once (all three partials at once = 48 KB and 144 VGPRs = three per CU
+  // and a second, mostly empty round: 70-79 us against 56-62 us on the same box)
+#define SIM_PART_PUT(SLOT)                                                                   \
+  _Pragma("unroll") for (int a = 0; a < ACH; ++a)                                            \
+      _Pragma("unroll") for (int j = 0; j < SVPT; ++j) part[SLOT][a * SVPT + j][lane] = acc[a][j];
+#define SIM_PART_ADD(SLOT)                                                                   \
+  _Pragma("unroll") for (int a = 0; a < ACH; ++a)                                            \
+      _Pragma("unroll") for (int j = 0; j < SVPT; ++j) acc[a][j] += part[SLOT][a * SVPT + j][lane];
+  // (every wave reaches all three barriers)
+  if (wave >= 2) SIM_PART_PUT(wave - 2)
+  __syncthreads();
+  if (wave < 2) SIM_PART_ADD(wave)
+  __syncthreads();
+  if (wave == 1) SIM_PART_PUT(0)
+  __syncthreads();
+  if (wave != 0) return;
+  SIM_PART_ADD(0)
+#undef SIM_PART_PUT
+#undef SIM_PART_ADD
+  sim_finish<BIG, ACT, SVPT>(acc, v0, nvox, ch, vnorm, expo, sim, maxbits);
 }
 
 __global__ __launch_bounds__(256) void sim_quantize(const float* __restrict__ sim, const unsigned* __restrict__ maxbits,
@@ -364,14 +431,23 @@ int accumulate_class_maps(const void* feat, bool half, int32_t f, int64_t nvox, 
       ch.count[i] = (float)(class_start_host[cc + 1] - class_start_host[cc]);
     }
     hipLaunchKernelGGL(transpose_queries, dim3((f * ACH + 255) / 256), dim3(256), 0, st, qf, f, a0, n, qf_t);
-    if (mode == 1)
-      hipLaunchKernelGGL((sim_accumulate<true, 0, true>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, expo, sim, maxbits);
-    else if (mode == 0)
-      hipLaunchKernelGGL((sim_accumulate<false, 0, true>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, expo, sim, maxbits);
-    else if (half)
-      hipLaunchKernelGGL((sim_accumulate<false, 1, true>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, expo, sim, maxbits);
-    else
-      hipLaunchKernelGGL((sim_accumulate<false, 1, false>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch, voxel_norm, expo, sim, maxbits);
+    // split-feature kernel when the shapes allow its 8- / 16-byte loads (VITTF_SIM_SPLIT=0: always the one-wave-per-voxel-pair kernel)
+    const char* split_env = getenv("VITTF_SIM_SPLIT");   // (read per call: the tests switch it)
+    const bool use_split = !split_env || atoi(split_env) != 0;
+    const bool split = use_split && f % 4 == 0 && nvox % 4 == 0 && ((uintptr_t)feat & 15) == 0;
+    const unsigned sblocks = (unsigned)((nvox / SVPT + 63) / 64);
+#define SIM_LAUNCH(BIG, ACT, HALF)                                                                                       \
+  {                                                                                                                      \
+    if (split) hipLaunchKernelGGL((sim_accumulate_split<BIG, ACT, HALF>), dim3(sblocks), dim3(256), 0, st, feat, f, nvox, \
+                                  qf_t, ch, voxel_norm, expo, sim, maxbits);                                             \
+    else hipLaunchKernelGGL((sim_accumulate<BIG, ACT, HALF>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch,   \
+                            voxel_norm, expo, sim, maxbits);                                                             \
+  }
+    if (mode == 1) SIM_LAUNCH(true, 0, true)
+    else if (mode == 0) SIM_LAUNCH(false, 0, true)
+    else if (half) SIM_LAUNCH(false, 1, true)
+    else SIM_LAUNCH(false, 1, false)
+#undef SIM_LAUNCH
     a0 += n;
   }
   return VITTF_OK;
