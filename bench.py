@@ -96,12 +96,12 @@ def host_cores():
     return max(1, min(n, int(os.environ.get('VITTF_CPU_THREADS', '16'))))
 
 
-def cpu_baseline(sd, vol, n_slices, im_sz):
+def cpu_baseline(sd, vol, n_slices, im_sz, arch='vits8'):
     """The oracle (CPU restatement of the reference path) on the host cores: batch-1 slice loop, fp32."""
     from oracle import dino_vit, feature_volume as ofv
     cores = host_cores()
     torch.set_num_threads(cores)
-    model = dino_vit.build_vit('vits8', sd)
+    model = dino_vit.build_vit(arch, sd)
     imgs = ofv.normalized_slices(vol.float(), 'z')
     pick = [imgs.shape[0] // 2 + i for i in range(n_slices + 1)]
     times = []
@@ -124,6 +124,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', type=str, default=None, choices=['64', '256', '512'])
     ap.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'fp16'])
+    ap.add_argument('--arch', type=str, default='vits8', choices=['vits8', 'vitb8'],
+                    help="vits8 = the BASELINE metric's model; vitb8 = configs[3]'s feature extractor (D = 768), informative")
     ap.add_argument('--engine-batch', type=int, default=32)
     ap.add_argument('--cpu-slices', type=int, default=5, help='slices timed for the CPU baseline (0 = skip)')
     args = ap.parse_args()
@@ -147,8 +149,10 @@ def main():
     torch.set_num_threads(max(1, host_cores() // max(1, min(world, 8))))   # host-side generation only
     wl = args.workload or ('256' if world == 1 else '512')
     vol, label, desc = make_workload(wl)
-    sd = vt.synthetic_state_dict('vits8', 0)
-    model = vt.HipViT(sd, 'vits8', args.dtype, device=dev)
+    desc = desc.replace('ViT-S/8', 'ViT-B/8 (D = 768)') if args.arch == 'vitb8' else desc
+    sd = vt.synthetic_state_dict(args.arch, 0)
+    model = vt.HipViT(sd, args.arch, args.dtype, device=dev)
+    dim, depth, heads, patch = vt.ARCHS[args.arch]
     dvol = vt.DeviceVolume(vol, dev)                     # the input is resident in HBM before the timed region
     ann = query_voxels(label)
     im_sz, feat_out = vt.sizing(dvol.shape, FOS, 8)
@@ -204,7 +208,7 @@ def main():
     sim_ms = (time.perf_counter() - ts) / n_rep * 1e3
     nvox = feat_out[0] * feat_out[1] * feat_out[2]
 
-    attn_f, lin_f, mlp_f, pe_f = vit_flops(n_tokens, 384, 12, 8)
+    attn_f, lin_f, mlp_f, pe_f = vit_flops(n_tokens, dim, depth, patch)
     slices_done = my_slices * args.steps
     if prof['mlp'][1] == 0:          # unfused MLP: its two GEMMs are counted in the gemm class
         lin_f, mlp_f = lin_f + mlp_f, 0
@@ -215,7 +219,7 @@ def main():
     peak = PEAK_TFLOPS[args.dtype]
     roofline = {
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-        'traffic': pmc_traffic(dom, args.engine_batch if my_slices >= args.engine_batch else my_slices),
+        'traffic': pmc_traffic(dom, args.engine_batch if my_slices >= args.engine_batch else my_slices) if args.arch == 'vits8' else None,
         'kernel': {'attention': f'attn_kernel<{args.dtype}>', 'gemm': f'gemm_kernel<{args.dtype}, *>',
                    'mlp': f'mlp_kernel<{args.dtype}>'}[dom],
         'launches': int(dom_launches), 'avg_launch_ms': round(dom_ms / max(1, dom_launches), 4),
@@ -228,20 +232,20 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'slices/sec (ViT-S/8, feature volume + 16-query similarity)', 'value': round(args.steps * total_slices / elapsed, 2),
+            'metric': f'slices/sec ({"ViT-S/8" if args.arch == "vits8" else "ViT-B/8"}, feature volume + 16-query similarity)', 'value': round(args.steps * total_slices / elapsed, 2),
             'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
             'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': desc, 'volume': list(dvol.shape), 'slices_per_step': total_slices,
                        'image': [im_sz[0], im_sz[1]], 'tokens': n_tokens, 'feature_volume': [384, *feat_out],
-                       'engine_batch': args.engine_batch, 'weights': 'seeded synthetic ViT-S/8 (seed 0)',
+                       'engine_batch': args.engine_batch, 'weights': f'seeded synthetic {args.arch} (seed 0)',
                        'parallelism': f'slices sharded over {world} rank(s), one all-gather per axis' if world > 1 else 'single GPU'},
             'roofline': roofline,
             'similarity': {'ms': round(sim_ms, 3), 'queries': 16, 'mvoxel_sim_per_s': round(nvox * 16 / 1e6 / (sim_ms * 1e-3), 1),
                            'mvoxel_per_s': round(nvox / 1e6 / (sim_ms * 1e-3), 1)},
         }
         if world == 1 and args.cpu_slices > 0:
-            out['cpu_baseline'] = cpu_baseline(sd, vol, args.cpu_slices, im_sz)
+            out['cpu_baseline'] = cpu_baseline(sd, vol, args.cpu_slices, im_sz, args.arch)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
