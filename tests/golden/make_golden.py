@@ -261,6 +261,26 @@ def refinement_case(ref_infer):
     return rec
 
 
+def samplers_case(ref_ntf):
+    """compare_feat_sampling.py:19-30 through predict_ntf's import: asked for more samples than the shell holds,
+    sample_surface returns the whole shell (index order), i.e. its deterministic candidate set; all structuring elements."""
+    g = torch.Generator().manual_seed(11)
+    shape = (20, 18, 24)
+    zz, yy, xx = torch.meshgrid(*[torch.linspace(-1, 1, n) for n in shape], indexing='ij')
+    blob = (zz ** 2 + 0.8 * yy ** 2 + 0.6 * xx ** 2) < 0.9                      # touches the volume border
+    labels = torch.zeros(shape, dtype=torch.uint8)
+    labels[blob] = 2
+    labels[(xx > 0.3) & blob] = 5
+    labels[torch.rand(shape, generator=g) < 0.04] = 0                              # pin holes
+    rec = {'labels': labels.numpy()}
+    for cls in (2, 5):
+        for dist in (1, 2, 3, 4):
+            mask = (labels == cls).numpy()
+            shell = quiet(ref_ntf.sample_surface, mask, 10 ** 6, dist_from_surface=dist)
+            rec[f'shell_c{cls}_d{dist}'] = shell.numpy().astype(np.int16)
+    return rec
+
+
 def ref_ntf_thresholds():
     return [0.486, 0.264, 0.236, 0.68, 0.291]      # predict_ntf.py:208 (a local of its __main__, restated)
 
@@ -289,6 +309,10 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
     ref_infer, ref_ntf, ref_syn = load_reference()
+    print('sample_surface candidate sets')
+    np.savez_compressed(os.path.join(HERE, 'samplers.npz'), **samplers_case(ref_ntf))
+    if '--only-samplers' in sys.argv:
+        return
     print('feature-volume cases (reference compute_qkv harness + oracle ViT)')
     for name, rec in feature_cases(ref_infer).items():
         np.savez_compressed(os.path.join(HERE, f'featvol_{name}.npz'), **rec)

@@ -680,6 +680,19 @@ def test_surface_shell_matches_scipy(gpu, shape, connectivity):
                           osmp.surface_shell(lab.numpy() == 3, connectivity))
 
 
+def test_surface_shell_golden(gpu, golden_dir):
+    """vittf_surface_shell / samplers.sample_surface against the reference's own sample_surface output
+    (tests/golden/samplers.npz: the whole shell in index order), both classes of one label upload, all elements."""
+    g = load_golden(golden_dir, 'samplers.npz')
+    dl = vt.samplers.device_labels(g['labels'])
+    for cls in (2, 5):
+        for dist in (1, 2, 3, 4):
+            want = torch.from_numpy(g[f'shell_c{cls}_d{dist}'].astype(np.int64))
+            assert torch.equal(vt.samplers.surface_shell(dl, dist, class_id=cls).nonzero().cpu(), want), (cls, dist)
+            assert torch.equal(vt.samplers.sample_surface(dl, 10 ** 6, dist_from_surface=dist, class_id=cls), want)
+            assert torch.equal(vt.samplers.sample_surface(g['labels'] == cls, 10 ** 6, dist_from_surface=dist), want)
+
+
 def test_samplers_draw_from_the_reference_candidate_sets(gpu):
     """sample_uniform / sample_surface / sample_both (compare_feat_sampling.py:13-33): distinct voxels, all inside the
     class mask / the scipy shell; fewer shell voxels than requested -> the whole shell in index order, like the reference."""

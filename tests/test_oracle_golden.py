@@ -146,3 +146,18 @@ def test_refinement_helpers_match_reference_golden(golden_dir):
         got = osim.take_most_dissimilar(x, 9, measure)
         assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, g[f'md_{measure}'].tolist()))
     assert osim.take_most_dissimilar(x[:5], 9) is not None and osim.take_most_dissimilar(x[:5], 9).shape[0] == 5
+
+
+def test_sampler_shell_matches_reference_golden(golden_dir):
+    """oracle/samplers.py against the reference's own sample_surface output (compare_feat_sampling.py:19-30, asked for more
+    samples than the shell holds -> the whole candidate set in index order), both classes, all structuring elements."""
+    from oracle import samplers as osmp
+    g = load_golden(golden_dir, 'samplers.npz')
+    labels = g['labels']
+    for cls in (2, 5):
+        for dist in (1, 2, 3, 4):
+            want = g[f'shell_c{cls}_d{dist}'].astype(np.int64)
+            shell = osmp.surface_shell(labels == cls, dist)
+            assert np.array_equal(np.argwhere(shell), want), (cls, dist)
+            got = osmp.sample_surface(labels == cls, 10 ** 6, dist_from_surface=dist)
+            assert np.array_equal(got.numpy(), want)
