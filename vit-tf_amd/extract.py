@@ -155,10 +155,12 @@ def _slab_shape_strides(axis, d, n, chunk):
 
 
 def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=DEFAULT_ENGINE_BATCH, part=1, group=None,
-                  ops=_HIP_OPS):
+                  ops=_HIP_OPS, pending=None):
     """Pooled (n_out windows along the slice dim) features of one axis, gathered over the process group.
 
-    Returns (gathered [world, D, *slab_dims] fp16 device tensor, chunk)."""
+    Returns (gathered [world, D, *slab_dims] fp16 device tensor, chunk).  With a `pending` list the exchange is only
+    enqueued (RCCL runs it on its own stream while the next axis is computed) and the caller finishes it with
+    `finish_exchanges(pending)` before it reads `gathered`."""
     world = torch.distributed.get_world_size(group) if _dist_on(group) else 1
     rank = torch.distributed.get_rank(group) if world > 1 else 0
     sl, a, b, n_slices, f0, f1 = _axis_geometry(dvol.shape, im_sizes, axis, model.patch_size)
@@ -176,21 +178,33 @@ def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=DEFAULT_ENGIN
         ops.pool(model, kbuf, s0, n_slices, n_out, win0, nwin, f0, f1, d, slab, strides)
         del kbuf
     if world > 1:
-        _all_gather_slabs(gathered, slab, group)      # the one exchange step per axis
+        handle = _all_gather_slabs(gathered, slab, group, defer=pending is not None)   # the one exchange step per axis
+        if handle is not None:
+            pending.append(handle)
     return gathered, chunk
 
 
-def _all_gather_slabs(gathered, slab, group):
+def finish_exchanges(pending):
+    """Make the current stream wait for the all-gathers enqueued with `pending` (no host synchronisation)."""
+    for work, _keep_alive in pending:
+        work.wait()
+    pending.clear()
+
+
+def _all_gather_slabs(gathered, slab, group, defer=False):
     """All-gather the ranks' pooled slabs into `gathered` ([world, ...], this rank's slab already in place).
-    RCCL (backend 'nccl') takes the single-tensor form; gloo (CPU tests, or a 2-ranks-on-1-GPU rehearsal) gets
-    the list form, staged through the host when the backend cannot take device tensors."""
+    RCCL (backend 'nccl') takes the single-tensor form -- asynchronously when `defer` is set: the (work, send buffer)
+    pair is returned and the collective overlaps whatever the caller enqueues next; gloo (CPU tests, or a
+    2-ranks-on-1-GPU rehearsal) gets the list form, staged through the host when the backend cannot take device tensors."""
     world = gathered.shape[0]
     flat = gathered.view(world, -1)
     mine = slab.reshape(-1).clone()
     backend = torch.distributed.get_backend(group)
     if backend == 'nccl':
+        if defer:
+            return torch.distributed.all_gather_into_tensor(flat.view(-1), mine, group=group, async_op=True), mine
         torch.distributed.all_gather_into_tensor(flat.view(-1), mine, group=group)
-        return
+        return None
     if flat.is_cuda:
         host = [torch.empty(flat.shape[1], dtype=flat.dtype) for _ in range(world)]
         torch.distributed.all_gather(host, mine.cpu(), group=group)
@@ -198,6 +212,7 @@ def _all_gather_slabs(gathered, slab, group):
             flat[r].copy_(host[r])
     else:
         torch.distributed.all_gather(list(flat.unbind(0)), mine, group=group)
+    return None
 
 
 def _dist_on(group):
@@ -227,10 +242,12 @@ def feature_volume(vol, model, feature_output_size=64, slice_along='all', engine
         return assemble_axis(g, slice_along, dvol.shape[sl])
     if slice_along != 'all':
         raise Exception(f'Invalid argument for --slice-along: {slice_along}. Must be x,y,z or all')
-    gathered, chunks = {}, [0, 0, 0]
+    gathered, chunks, pending = {}, [0, 0, 0], []
     for ax in ('z', 'y', 'x'):
         sl = AXIS_DIMS[ax][0]
-        gathered[ax], chunks[sl] = axis_features(model, dvol, ax, im_sz, feat_out[sl], engine_batch, part, group, ops)
+        gathered[ax], chunks[sl] = axis_features(model, dvol, ax, im_sz, feat_out[sl], engine_batch, part, group, ops,
+                                                 pending=pending)
+    finish_exchanges(pending)        # the z and y exchanges have run under the compute of the following axes
     world = gathered['z'].shape[0]
     out = ops.assemble_sum(model, gathered['z'], gathered['y'], gathered['x'], world, chunks, model.embed_dim, feat_out)
     return out.squeeze()        # the reference's running sum drops singleton dims (infer.py:332 v.squeeze())
