@@ -167,7 +167,7 @@ def main():
 
     def step():
         feats = vt.feature_volume(None, model, FOS, 'all', args.engine_batch, dvol=dvol)
-        sims = vt.compute_similarities(vol, feats, ann)
+        sims = vt.compute_similarities(vol, feats, ann, keep_on_device=True)     # maps feed the label kernel directly
         return feats, vt.assign_labels(sims)
 
     for _ in range(args.warmup):

@@ -32,10 +32,11 @@ ct_org_names = ['liver', 'bladder', 'lung', 'kidney', 'bone']
 ct_org_thresholds = [0.486, 0.264, 0.236, 0.68, 0.291]
 
 
-def compute_similarities(volume, features, annotations, bilateral_solver=False):
+def compute_similarities(volume, features, annotations, bilateral_solver=False, keep_on_device=False):
     """(:24-101) volume (W, H, D), features (F, W', H', D'), annotations {name: (N, 3)} ->
-    {name: uint8 (W//2, H//2, D//2)} (CPU tensors)."""
-    return vt.compute_similarities(volume, features, annotations, bilateral_solver=bilateral_solver)
+    {name: uint8 (W//2, H//2, D//2)} (CPU tensors like the reference's, unless keep_on_device)."""
+    return vt.compute_similarities(volume, features, annotations, bilateral_solver=bilateral_solver,
+                                   keep_on_device=keep_on_device)
 
 
 def assign_labels(similarities):
@@ -114,9 +115,11 @@ def main(argv=None):
     else:
         t1 = time.time()
         if sum(int(torch.as_tensor(v).shape[0]) for v in annotations.values()) > 10000:     # (:185-187) one class per call
-            similarities = {k: compute_similarities(volume, features, {k: v})[k] for k, v in annotations.items()}
+            similarities = {k: compute_similarities(volume, features, {k: v}, bilateral_solver=args.bilateral_solver,
+                                                    keep_on_device=True)[k] for k, v in annotations.items()}
         else:
-            similarities = compute_similarities(volume, features, annotations)
+            similarities = compute_similarities(volume, features, annotations, bilateral_solver=args.bilateral_solver,
+                                                keep_on_device=True)
         torch.cuda.synchronize()
         t2 = time.time()
     print('Similarities:', {k: v.shape for k, v in similarities.items()})

@@ -217,6 +217,22 @@ def test_entry_points_end_to_end(gpu, tmp_path):
     pred_bls = np.load(d / 'ntf_pred16.0uniformbls.npy')
     assert pred_bls.dtype == np.uint8 and pred_bls.shape == (16, 16, 16)
     assert {'mIoU', 'confusion_matrix'} <= set(json.load(open(d / 'ntf_metrics16.0uniformbls.json')))
+    # fixed annotations (--num-samples 0 reads annotations.npy): the flag must change what is computed, and both outputs
+    # must equal the in-process calls on the inputs predict_ntf.py prepares (volume / labels flipped on axis -3)
+    vol = np.flip(np.load(d / 'volume.npy').astype(np.float32), axis=-3).copy()
+    lab = np.flip(np.load(d / 'labels.npy'), axis=-3).copy()
+    inside = np.argwhere(lab == 1)
+    ann = {'ntf1': torch.from_numpy(inside[:: max(1, len(inside) // 12)][:12].copy())}
+    np.save(d / 'annotations.npy', {k: v.numpy() for k, v in ann.items()})
+    for flag, tag in ((), 'annotated'), (('--bilateral-solver',), 'annotatedbls'):
+        r = run('predict_ntf.py', '--data', str(d), *flag)
+        assert r.returncode == 0, r.stderr + r.stdout
+    got, got_bls = np.load(d / 'ntf_pred0.0annotated.npy'), np.load(d / 'ntf_pred0.0annotatedbls.npy')
+    ft = torch.from_numpy(feats['k'])
+    want = vt.assign_labels(vt.compute_similarities(vol, ft, ann))
+    want_bls = vt.assign_labels(vt.compute_similarities(vol, ft, ann, bilateral_solver=True))
+    assert np.array_equal(got, want) and np.array_equal(got_bls, want_bls)
+    assert not np.array_equal(want, want_bls), 'the solver changed nothing: the case does not tell the two paths apart'
 
 
 def test_two_ranks_share_one_gpu_rehearsal(gpu, tmp_path):

@@ -58,7 +58,8 @@ def sample_features3d(feat_vol, rel_coords, mode='nearest'):
     return out
 
 
-def compute_similarities(volume, features, annotations, bilateral_solver=False, device=None, normalize=False):
+def compute_similarities(volume, features, annotations, bilateral_solver=False, device=None, normalize=False,
+                         keep_on_device=False):
     """predict_ntf.py:24-101.  volume: (W, H, D) array/tensor (only its shape is used unless bilateral_solver);
     features: (F, W', H', D'); annotations: {name: (n, 3) voxel coords}.
     bilateral_solver=True: every class map is refined by the 3-D bilateral solver against the volume
@@ -66,7 +67,9 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
     Returns {name: uint8 CPU tensor (W//2, H//2, D//2)}; None when there is nothing to query
     (predict_ntf.py:51-55).  Classes with zero annotations are skipped.
     normalize=True: cosine similarity -- the volume is L2-normalised per voxel first, as
-    compare_feat_sampling.py:45 and tests/test_vishum.py:12 do (predict_ntf.py itself does not)."""
+    compare_feat_sampling.py:45 and tests/test_vishum.py:12 do (predict_ntf.py itself does not).
+    keep_on_device=True: the maps stay on the GPU (for assign_labels / further kernels) instead of the reference's
+    CPU tensors: at 512^3 the (256, 256, 256) uint8 maps are 17 MB per class, 2 ms of copies for a 0.3 ms query."""
     if len(annotations) == 0:
         return None
     names = [k for k, v in annotations.items() if torch.as_tensor(v).shape[0] > 0]
@@ -108,24 +111,26 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
         res = {}
         for i, k in enumerate(names):
             refined = bilateral.refine_similarity(maps[i], vol, sim_shape)
-            res[k] = bilateral.quantize_u8(refined).cpu()
+            q = bilateral.quantize_u8(refined)
+            res[k] = q if keep_on_device else q.cpu()
         return res
     out = torch.empty((nclass, *sim_shape), dtype=torch.uint8, device=dev)
     _lib.check(lib.vittf_similarity(_lib.ptr(feat), f, n0, n1, n2, _lib.ptr(qf),
                                     starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big, _lib.ptr(vnorm),
                                     sim_shape[0], sim_shape[1], sim_shape[2], _lib.ptr(out), _lib.ptr(ws), ws_bytes,
                                     _lib.stream_ptr()), 'vittf_similarity')
-    host = out.cpu()
+    host = out if keep_on_device else out.cpu()
     return {k: host[i] for i, k in enumerate(names)}
 
 
 def assign_labels(similarities, thresholds=CT_ORG_THRESHOLDS, device=None):
-    """predict_ntf.py:203-215: list/dict of uint8 class maps (annotation order) -> uint8 label volume (numpy)."""
+    """predict_ntf.py:203-215: list/dict of uint8 class maps (annotation order; CPU or GPU tensors / arrays) -> uint8
+    label volume (numpy)."""
     lib = _lib.require_device()
     dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
     maps = list(similarities.values()) if isinstance(similarities, dict) else list(similarities)
     maps = maps[:len(thresholds)]                       # zip() with the 5 CT-ORG names, predict_ntf.py:211
-    sims = torch.stack([torch.as_tensor(m).to(torch.uint8) for m in maps]).to(dev).contiguous()
+    sims = torch.stack([torch.as_tensor(m).to(dev, torch.uint8) for m in maps]).contiguous()
     n = sims[0].numel()
     thr = (C.c_int32 * len(maps))(*[int(t * 255) for t in thresholds[:len(maps)]])
     labels = torch.empty(sims.shape[1:], dtype=torch.uint8, device=dev)
