@@ -13,14 +13,14 @@
 //   occupancy table over the key space -> exclusive prefix sum = vertex ids in the reference's order ->
 //   per-vertex index of the 8 neighbours (+-1 in x, y, z, luma; -1 = absent).
 // splat = atomic adds (int counts, fp64 sums), blur(y)_i = 12 y_i + sum of present neighbours, slice = gather.
-// Bistochastisation and the whole CG run inside ONE workgroup (1024 threads striding over the vertices, fp64,
-// LDS tree reductions in a fixed order): the vectors are a few 10^4..10^6 long and the iteration is a chain of
-// dependent dot products, so a single workgroup without launch gaps is both fast enough (the post-process is a
-// few ms against seconds on SciPy) and deterministic.  All arithmetic that the reference does in fp64 is fp64 here;
+// Bistochastisation and the CG are one launch per phase over all vertices (fp64; per-workgroup tree reductions whose
+// partials every workgroup then adds in the same fixed order, so dot products are deterministic; convergence latched
+// in a device flag, no host round trip).  All arithmetic that the reference does in fp64 is fp64 here;
 // the fp32 parts (resize, Sobel) use unfused multiply / add in the CPU operators' order.
 #include "vittf_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -66,12 +66,34 @@ __global__ __launch_bounds__(BT) void to_u8_kernel(const float* __restrict__ v, 
 // bounding box of sim > thresh: bounds = {min0, min1, min2, max0, max1, max2} (initialised to INT_MAX / -1)
 __global__ __launch_bounds__(BT) void bbox_kernel(const float* __restrict__ sim, int d0, int d1, int d2, float thresh,
                                                   int* __restrict__ bounds) {
-  const int64_t idx = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (idx >= (int64_t)d0 * d1 * d2) return;
-  if (!(sim[idx] > thresh)) return;
-  const int x = (int)(idx % d2), y = (int)((idx / d2) % d1), z = (int)(idx / ((int64_t)d1 * d2));
-  atomicMin(bounds + 0, z); atomicMin(bounds + 1, y); atomicMin(bounds + 2, x);
-  atomicMax(bounds + 3, z); atomicMax(bounds + 4, y); atomicMax(bounds + 5, x);
+  __shared__ int red[6][BT / 64];
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+  const int64_t n = (int64_t)d0 * d1 * d2;
+  for (int64_t idx = (int64_t)blockIdx.x * BT + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * BT) {
+    if (sim[idx] > thresh) {
+      const int x = (int)(idx % d2), y = (int)((idx / d2) % d1), z = (int)(idx / ((int64_t)d1 * d2));
+      lo[0] = min(lo[0], z); lo[1] = min(lo[1], y); lo[2] = min(lo[2], x);
+      hi[0] = max(hi[0], z); hi[1] = max(hi[1], y); hi[2] = max(hi[2], x);
+    }
+  }
+  // thread, wave, then workgroup reduction: 6 atomics per workgroup of a 1024-workgroup grid instead of 6 per voxel
+  // above the threshold (4 ms at 256^3)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[i] = min(lo[i], __shfl_xor(lo[i], off));
+      hi[i] = max(hi[i], __shfl_xor(hi[i], off));
+    }
+    if ((threadIdx.x & 63) == 0) { red[i][threadIdx.x >> 6] = lo[i]; red[3 + i][threadIdx.x >> 6] = hi[i]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    int v = red[threadIdx.x][0];
+    for (int w = 1; w < BT / 64; ++w) v = threadIdx.x < 3 ? min(v, red[threadIdx.x][w]) : max(v, red[threadIdx.x][w]);
+    if (threadIdx.x < 3) { if (v != 0x7fffffff) atomicMin(bounds + threadIdx.x, v); }
+    else if (v >= 0) atomicMax(bounds + threadIdx.x, v);
+  }
 }
 
 struct Box { int lo0, lo1, lo2, c0, c1, c2, d1, d2; };   // crop origin / extent inside a (., d1, d2) volume
@@ -123,15 +145,34 @@ __global__ __launch_bounds__(BT) void key_kernel(const unsigned char* __restrict
   occupied[k] = 1;
 }
 
-// exclusive prefix sum of `occupied` (0 / 1) in one workgroup: rank[k] = vertex id of key k; total -> *nvert
-__global__ __launch_bounds__(1024) void rank_kernel(const int* __restrict__ occupied, int nkeys, int* __restrict__ rank,
-                                                    int* __restrict__ nvert) {
+// exclusive prefix sum of `occupied` (0 / 1): rank[k] = vertex id of key k; total -> *nvert.  Three launches: sums of
+// blocks of RANK_CHUNK keys, a one-workgroup scan of those sums, then the ranks inside every block (one workgroup over
+// the ~2 M keys of a 256^3 crop took 1.7 ms).
+constexpr int RANK_CHUNK = 1024;
+__global__ __launch_bounds__(BT) void rank_sums_kernel(const int* __restrict__ occupied, int nkeys, int* __restrict__ block_sum) {
+  __shared__ int red[BT / 64];
+  const int base = blockIdx.x * RANK_CHUNK;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < RANK_CHUNK / BT; ++j) {
+    const int k = base + j * BT + threadIdx.x;
+    if (k < nkeys) s += occupied[k];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// in place: block_sum[b] -> sum of the blocks before b; *nvert = total
+__global__ __launch_bounds__(1024) void rank_scan_kernel(int* __restrict__ block_sum, int nblocks, int* __restrict__ nvert) {
   __shared__ int part[1024];
   const int tid = threadIdx.x;
-  const int per = (nkeys + 1023) / 1024;
-  const int lo = tid * per, hi = min(nkeys, lo + per);
+  const int per = (nblocks + 1023) / 1024;
+  const int lo = tid * per, hi = min(nblocks, lo + per);
   int s = 0;
-  for (int k = lo; k < hi; ++k) s += occupied[k];
+  for (int k = lo; k < hi; ++k) s += block_sum[k];
   part[tid] = s;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {     // Hillis-Steele inclusive scan
@@ -141,8 +182,30 @@ __global__ __launch_bounds__(1024) void rank_kernel(const int* __restrict__ occu
     __syncthreads();
   }
   int run = part[tid] - s;
-  for (int k = lo; k < hi; ++k) { rank[k] = run; run += occupied[k]; }
+  for (int k = lo; k < hi; ++k) { const int v = block_sum[k]; block_sum[k] = run; run += v; }
   if (tid == 1023) *nvert = part[1023];
+}
+
+__global__ __launch_bounds__(BT) void rank_kernel(const int* __restrict__ occupied, int nkeys, const int* __restrict__ block_off,
+                                                  int* __restrict__ rank) {
+  __shared__ int wave_tot[BT / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int run = block_off[blockIdx.x];
+#pragma unroll 1
+  for (int j = 0; j < RANK_CHUNK / BT; ++j) {
+    const int k = blockIdx.x * RANK_CHUNK + j * BT + threadIdx.x;
+    const int v = k < nkeys ? occupied[k] : 0;
+    const unsigned long long mask = __ballot(v != 0);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(mask);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BT / 64; ++w) { if (w < wave) off += wave_tot[w]; tot += wave_tot[w]; }
+    if (k < nkeys) rank[k] = run + off + before;
+    run += tot;
+    __syncthreads();
+  }
 }
 
 // splat: per-vertex voxel count, confidence sum and confidence-weighted target sum; the voxel -> vertex map
@@ -152,15 +215,37 @@ __global__ __launch_bounds__(BT) void splat_kernel(const unsigned* __restrict__ 
                                                    int* __restrict__ vertex_of_voxel, int* __restrict__ count,
                                                    double* __restrict__ w_splat, double* __restrict__ b_splat) {
   const int64_t idx = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (idx >= n) return;
-  const int v = rank[key[idx]];
-  vertex_of_voxel[idx] = v;
-  const int x = (int)(idx % b.c2), y = (int)((idx / b.c2) % b.c1), z = (int)(idx / ((int64_t)b.c1 * b.c2));
-  const double t = (double)sim[((int64_t)(b.lo0 + z) * b.d1 + (b.lo1 + y)) * b.d2 + (b.lo2 + x)];
-  const double c = (double)__fsub_rn(__uint_as_float(*gmax_bits), g[idx]);   // confidence = max - Sobel, fp32 then double
-  atomicAdd(count + v, 1);
-  atomicAdd(w_splat + v, c);
-  atomicAdd(b_splat + v, t * c);
+  const bool live = idx < n;
+  int v = -1;
+  int cnt = 0;
+  double c = 0.0, tc = 0.0;
+  if (live) {
+    v = rank[key[idx]];
+    vertex_of_voxel[idx] = v;
+    const int x = (int)(idx % b.c2), y = (int)((idx / b.c2) % b.c1), z = (int)(idx / ((int64_t)b.c1 * b.c2));
+    const double t = (double)sim[((int64_t)(b.lo0 + z) * b.d1 + (b.lo1 + y)) * b.d2 + (b.lo2 + x)];
+    c = (double)__fsub_rn(__uint_as_float(*gmax_bits), g[idx]);   // confidence = max - Sobel, fp32 then double
+    tc = t * c;
+    cnt = 1;
+  }
+  // neighbours along x share a grid cell (and mostly a luma bin): runs of equal vertex ids inside the wave are summed
+  // in the lanes (segmented suffix sums) and only the head of a run goes to memory -- a fifth of the atomics
+  const int lane = threadIdx.x & 63;
+  const int vnext = __shfl_down(v, 1);
+  int ended = (lane == 63 || vnext != v) ? 1 : 0;      // my partial sum already reaches the end of my run
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {             // segmented suffix sums by doubling
+    const int co = __shfl_down(cnt, off), eo = __shfl_down(ended, off);
+    const double cc = __shfl_down(c, off), tt = __shfl_down(tc, off);
+    if (!ended && lane + off < 64) { cnt += co; c += cc; tc += tt; ended = eo; }
+  }
+  const int vprev = __shfl_up(v, 1);
+  const bool head = live && (lane == 0 || vprev != v);
+  if (head) {
+    atomicAdd(count + v, cnt);
+    atomicAdd(w_splat + v, c);
+    atomicAdd(b_splat + v, tc);
+  }
 }
 
 // neighbour table: nb[dir][vertex], dir = 2 * dim + (step > 0), dims x, y, z, luma
@@ -300,6 +385,160 @@ __global__ __launch_bounds__(1024) void solve_kernel(SolveArgs a) {
   }
 }
 
+// ---- the same solver spread over the chip: one launch per phase instead of one workgroup for everything ----------
+// (77 k vertices, ~45 dependent vector passes: 16.5 ms in one workgroup.)  Every dot product is reduced in two fixed
+// steps -- a tree inside each workgroup, then every workgroup adds the per-workgroup partials in the same order -- so the
+// result does not depend on scheduling.  Convergence (SciPy's test, at the top of an iteration) is decided identically
+// by every workgroup from those partials and latched in `done`, after which the remaining launches return at once.
+struct SolveScratch {
+  double *bb, *anyx, *rr[2], *rho[2], *pq;   // per-workgroup partial sums
+  int* done;
+  int nblk;
+};
+
+__device__ __forceinline__ double wg_sum(double v, double* red) {   // BT threads, fixed tree
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+#pragma unroll
+  for (int s = BT / 2; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double out = red[0];
+  __syncthreads();
+  return out;
+}
+// `done` as ONE value per workgroup (workgroup 0 may set it while others start the same kernel: every thread of a
+// workgroup must take the same branch in front of the barriers below)
+__device__ __forceinline__ bool wg_done(const int* done) {
+  __shared__ int flag;
+  if (threadIdx.x == 0) flag = *done;
+  __syncthreads();
+  const bool d = flag != 0;
+  __syncthreads();
+  return d;
+}
+__device__ __forceinline__ double all_sum(const double* __restrict__ part, int nblk, double* red) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += BT) v += part[i];
+  return wg_sum(v, red);
+}
+
+__global__ __launch_bounds__(BT) void bs_step_kernel(SolveArgs a, const double* __restrict__ n_in, double* __restrict__ n_out,
+                                                     int first) {
+  const int i = blockIdx.x * BT + threadIdx.x;
+  if (i >= a.nvert) return;
+  if (first) { n_out[i] = 1.0; return; }
+  n_out[i] = sqrt(n_in[i] * (double)a.count[i] / blur_at(n_in, a.nb, a.nvert_cap, i));
+}
+
+// m = n blur(n); diag(A), flat initialisation, |b|^2 and any(x0) partials; tmp = n x0 for the first A x
+__global__ __launch_bounds__(BT) void cg_setup_kernel(SolveArgs a, SolveScratch sc) {
+  __shared__ double red[BT];
+  const int i = blockIdx.x * BT + threadIdx.x;
+  double bb = 0.0, anyx = 0.0;
+  if (i < a.nvert) {
+    const double ni = a.n[i];
+    const double mi = ni * blur_at(a.n, a.nb, a.nvert_cap, i);
+    a.m[i] = mi;
+    const double d = a.lam * (mi - ni * 12.0 * ni) + a.w_splat[i];
+    a.inv_diag[i] = 1.0 / fmax(d, a.a_diag_min);
+    const double x0 = a.b[i] / a.w_splat[i];     // flat initialisation splat(x w) / splat(w)
+    a.x[i] = x0;
+    a.tmp[i] = ni * x0;
+    bb = a.b[i] * a.b[i];
+    anyx = (x0 != 0.0) ? 1.0 : 0.0;              // NaN counts as "any", like ndarray.any()
+  }
+  bb = wg_sum(bb, red);
+  anyx = wg_sum(anyx, red);
+  if (threadIdx.x == 0) { sc.bb[blockIdx.x] = bb; sc.anyx[blockIdx.x] = anyx; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *sc.done = 0;
+}
+
+// r = b - A x0 (or b when x0 is all zero); |b| = 0: x = b and done (scipy returns b at once); partials of r.r, r.Dr
+__global__ __launch_bounds__(BT) void cg_residual_kernel(SolveArgs a, SolveScratch sc) {
+  __shared__ double red[BT];
+  const double bnorm = sqrt(all_sum(sc.bb, sc.nblk, red));
+  const double anyx = all_sum(sc.anyx, sc.nblk, red);
+  const int i = blockIdx.x * BT + threadIdx.x;
+  if (bnorm == 0.0) {
+    if (i < a.nvert) a.x[i] = a.b[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sc.done = 1;
+    return;
+  }
+  double rr = 0.0, rho = 0.0;
+  if (i < a.nvert) {
+    double r = a.b[i];
+    if (anyx != 0.0)
+      r -= a.lam * (a.m[i] * a.x[i] - a.n[i] * blur_at(a.tmp, a.nb, a.nvert_cap, i)) + a.w_splat[i] * a.x[i];
+    a.r[i] = r;
+    rr = r * r;
+    rho = r * (a.inv_diag[i] * r);
+  }
+  rr = wg_sum(rr, red);
+  rho = wg_sum(rho, red);
+  if (threadIdx.x == 0) { sc.rr[0][blockIdx.x] = rr; sc.rho[0][blockIdx.x] = rho; }
+}
+
+// top of iteration `it`: convergence test, then p = z + beta p and tmp = n p
+__global__ __launch_bounds__(BT) void cg_p_kernel(SolveArgs a, SolveScratch sc, int it) {
+  __shared__ double red[BT];
+  if (wg_done(sc.done)) return;
+  const int cur = it & 1;
+  const double rr = all_sum(sc.rr[cur], sc.nblk, red);
+  const double atol = a.rtol * sqrt(all_sum(sc.bb, sc.nblk, red));
+  if (sqrt(rr) < atol) {                         // NaN compares false: the loop runs on, as in the reference
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sc.done = 1;
+    return;
+  }
+  const double rho = all_sum(sc.rho[cur], sc.nblk, red);
+  const double beta = it > 0 ? rho / all_sum(sc.rho[cur ^ 1], sc.nblk, red) : 0.0;
+  const int i = blockIdx.x * BT + threadIdx.x;
+  if (i < a.nvert) {
+    const double z = a.inv_diag[i] * a.r[i];
+    const double p = it > 0 ? a.p[i] * beta + z : z;
+    a.p[i] = p;
+    a.tmp[i] = a.n[i] * p;
+  }
+}
+
+// q = A p and the partials of p.q
+__global__ __launch_bounds__(BT) void cg_q_kernel(SolveArgs a, SolveScratch sc) {
+  __shared__ double red[BT];
+  if (wg_done(sc.done)) return;
+  const int i = blockIdx.x * BT + threadIdx.x;
+  double pq = 0.0;
+  if (i < a.nvert) {
+    const double p = a.p[i];
+    const double q = a.lam * (a.m[i] * p - a.n[i] * blur_at(a.tmp, a.nb, a.nvert_cap, i)) + a.w_splat[i] * p;
+    a.q[i] = q;
+    pq = p * q;
+  }
+  pq = wg_sum(pq, red);
+  if (threadIdx.x == 0) sc.pq[blockIdx.x] = pq;
+}
+
+// x += alpha p, r -= alpha q and the partials of the new r.r, r.Dr (for iteration it + 1)
+__global__ __launch_bounds__(BT) void cg_x_kernel(SolveArgs a, SolveScratch sc, int it) {
+  __shared__ double red[BT];
+  if (wg_done(sc.done)) return;
+  const int cur = it & 1;
+  const double alpha = all_sum(sc.rho[cur], sc.nblk, red) / all_sum(sc.pq, sc.nblk, red);
+  const int i = blockIdx.x * BT + threadIdx.x;
+  double rr = 0.0, rho = 0.0;
+  if (i < a.nvert) {
+    a.x[i] += alpha * a.p[i];
+    const double r = a.r[i] - alpha * a.q[i];
+    a.r[i] = r;
+    rr = r * r;
+    rho = r * (a.inv_diag[i] * r);
+  }
+  rr = wg_sum(rr, red);
+  rho = wg_sum(rho, red);
+  if (threadIdx.x == 0) { sc.rr[cur ^ 1][blockIdx.x] = rr; sc.rho[cur ^ 1][blockIdx.x] = rho; }
+}
+
 // slice + torch.nan_to_num + write_crop_into
 __global__ __launch_bounds__(BT) void slice_kernel(const double* __restrict__ x, const int* __restrict__ vertex_of_voxel, Box b,
                                                    int64_t n, float* __restrict__ sim) {
@@ -346,7 +585,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 unsigned blocks_for(int64_t n) { return (unsigned)((n + BT - 1) / BT); }
 
 struct Layout {
-  size_t vol_r, vol_u8, bounds, gmax, minmax, mm_ws, nvert, luma, g, key, vov, occupied, rank, count, nb, vecs, total;
+  size_t vol_r, vol_u8, bounds, gmax, minmax, mm_ws, nvert, luma, g, key, vov, occupied, rank, rank_blocks, count, nb, vecs, partials, total;
   int64_t nvox; int nkeys_cap; int nvert_cap;
 };
 
@@ -366,6 +605,8 @@ Layout make_layout(int o0, int o1, int o2, double sigma_spatial, int luma_bins) 
   L.occupied = take((size_t)L.nkeys_cap * 4); L.rank = take((size_t)L.nkeys_cap * 4);
   L.count = take((size_t)L.nvert_cap * 4); L.nb = take((size_t)L.nvert_cap * 8 * 4);
   L.vecs = take((size_t)L.nvert_cap * 8 * 10);   // w_splat, b, m, n, x, r, p, q, inv_diag, tmp
+  L.rank_blocks = take(((size_t)L.nkeys_cap / RANK_CHUNK + 1) * 4);
+  L.partials = take(((size_t)L.nvert_cap / BT + 1) * 8 * 7 + 256);   // bb, anyx, rr[2], rho[2], pq per workgroup + done
   L.total = off;
   return L;
 }
@@ -420,7 +661,8 @@ extern "C" int vittf_bilateral_refine(const float* sim_in, int32_t n0, int32_t n
   // ---- crop_pad (bilateral_solver3d.py:183-204) ----
   const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1};
   if (hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return VITTF_ERR_LAUNCH;
-  hipLaunchKernelGGL(bbox_kernel, dim3(blocks_for(nvox)), dim3(BT), 0, st, sim_out, o0, o1, o2, prm->crop_threshold, bounds);
+  hipLaunchKernelGGL(bbox_kernel, dim3(blocks_for(nvox) < 1024 ? blocks_for(nvox) : 1024), dim3(BT), 0, st, sim_out, o0, o1, o2,
+                     prm->crop_threshold, bounds);
   int hb[6];
   if (hipMemcpyAsync(hb, bounds, sizeof(hb), hipMemcpyDeviceToHost, st) != hipSuccess) return VITTF_ERR_LAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return VITTF_ERR_LAUNCH;
@@ -456,7 +698,13 @@ extern "C" int vittf_bilateral_refine(const float* sim_in, int32_t n0, int32_t n
   (void)hipMemsetAsync(occupied, 0, (size_t)nkeys * 4, st);
   hipLaunchKernelGGL(sobel_kernel, dim3(blocks_for(n)), dim3(BT), 0, st, vol_u8, b, g, gmax);
   hipLaunchKernelGGL(key_kernel, dim3(blocks_for(n)), dim3(BT), 0, st, vol_u8, b, luma_d, prm->sigma_spatial, kd, key, occupied);
-  hipLaunchKernelGGL(rank_kernel, dim3(1), dim3(1024), 0, st, occupied, nkeys, rank, nvert_d);
+  {
+    int* block_off = (int*)(w + L.rank_blocks);
+    const int rb = (nkeys + RANK_CHUNK - 1) / RANK_CHUNK;
+    hipLaunchKernelGGL(rank_sums_kernel, dim3(rb), dim3(BT), 0, st, occupied, nkeys, block_off);
+    hipLaunchKernelGGL(rank_scan_kernel, dim3(1), dim3(1024), 0, st, block_off, rb, nvert_d);
+    hipLaunchKernelGGL(rank_kernel, dim3(rb), dim3(BT), 0, st, occupied, nkeys, block_off, rank);
+  }
   int nvert = 0;
   if (hipMemcpyAsync(&nvert, nvert_d, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return VITTF_ERR_LAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return VITTF_ERR_LAUNCH;
@@ -474,7 +722,33 @@ extern "C" int vittf_bilateral_refine(const float* sim_in, int32_t n0, int32_t n
   hipLaunchKernelGGL(splat_kernel, dim3(blocks_for(n)), dim3(BT), 0, st, key, rank, g, gmax, sim_out, b, n, vov, count,
                      vecs, vecs + cap);
   hipLaunchKernelGGL(neighbour_kernel, dim3(blocks_for(nkeys)), dim3(BT), 0, st, occupied, rank, kd, nkeys, cap, nb);
-  hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(1024), 0, st, a);
+  static const bool wide_solver = [] { const char* e = getenv("VITTF_BLS_SOLVER"); return !e || atoi(e) != 0; }();
+  if (!wide_solver) {
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(1024), 0, st, a);     // everything in one workgroup (first version)
+  } else {
+    SolveScratch sc{};
+    sc.nblk = (nvert + BT - 1) / BT;
+    const size_t pstride = (size_t)cap / BT + 1;
+    double* pbase = (double*)(w + L.partials);
+    sc.bb = pbase; sc.anyx = pbase + pstride; sc.rr[0] = pbase + 2 * pstride; sc.rr[1] = pbase + 3 * pstride;
+    sc.rho[0] = pbase + 4 * pstride; sc.rho[1] = pbase + 5 * pstride; sc.pq = pbase + 6 * pstride;
+    sc.done = (int*)(pbase + 7 * pstride);
+    const dim3 grid(sc.nblk), block(BT);
+    // n = 1; bistoch_iters x: n = sqrt(n m0 / blur(n)), ping-pong between a.n and a.p (free until the CG starts)
+    double* nbuf[2] = {a.n, a.p};
+    hipLaunchKernelGGL(bs_step_kernel, grid, block, 0, st, a, nbuf[1], nbuf[0], 1);
+    int cur = 0;
+    for (int it = 0; it < a.bistoch_iters; ++it, cur ^= 1)
+      hipLaunchKernelGGL(bs_step_kernel, grid, block, 0, st, a, nbuf[cur], nbuf[cur ^ 1], 0);
+    if (cur == 1 && hipMemcpyAsync(a.n, a.p, (size_t)nvert * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return VITTF_ERR_LAUNCH;
+    hipLaunchKernelGGL(cg_setup_kernel, grid, block, 0, st, a, sc);
+    hipLaunchKernelGGL(cg_residual_kernel, grid, block, 0, st, a, sc);
+    for (int it = 0; it < a.maxiter; ++it) {
+      hipLaunchKernelGGL(cg_p_kernel, grid, block, 0, st, a, sc, it);
+      hipLaunchKernelGGL(cg_q_kernel, grid, block, 0, st, a, sc);
+      hipLaunchKernelGGL(cg_x_kernel, grid, block, 0, st, a, sc, it);
+    }
+  }
   hipLaunchKernelGGL(slice_kernel, dim3(blocks_for(n)), dim3(BT), 0, st, a.x, vov, b, n, sim_out);
   return vittf_check_launch();
 }
