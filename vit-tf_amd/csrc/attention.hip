@@ -38,8 +38,10 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
                                           const char* va0, const char* va1, const s16x8_t& q0, const s16x8_t& q1,
                                           const s16x8_t& q2, const s16x8_t& q3, f32x16_t& o0, f32x16_t& o1,
                                           f32x16_t& negm, float& m_run, float& l_run, int t, int tokens, int h, float c) {
-  // Two 32-key halves, each carried from S^T to O^T before the next one starts: the score registers (16) and
-  // the P fragments (8) of one half are all that is live, which keeps the kernel at 4 waves per SIMD.
+  // Two 32-key halves, each carried from S^T to O^T: the score registers (16) and the P fragments (8) of one half are
+  // (nearly) all that is live.  The halves are NOT fenced off from each other any more: within the register budget of
+  // the launch bounds hipcc sinks the O^T MFMAs of one half into the exp2 stream of the next (an `s_nop 10` behind the
+  // S^T chain otherwise idles the wave): -1.5 % per launch in the pipeline, no spills (168 / 128 VGPRs).
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
     constexpr int kb = BUF * BUF_BYTES;
@@ -163,7 +165,6 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
         else          o1 = mfma32<DT>(vf, pf[s2], o1);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);   // keep the halves sequential: interleaving them costs 40 VGPRs and a wave per SIMD
   }
 }
 
