@@ -448,6 +448,21 @@ def test_cosine_similarity_option(gpu, sim_split):
         d = torch.minimum(d, 256 - d)
         assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, k
         assert not torch.equal(got[k], raw[k])                   # and it is not the un-normalised map
+    again = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann, voxel_norm=norms)   # norms passed in
+    assert all(torch.equal(again[k], got[k]) for k in ann)
+
+
+def test_voxel_norm_kernels(gpu):
+    """vittf_voxel_norm: the split kernel (F % 4 == 0, voxels % 4 == 0) and the plain one on ragged shapes, against
+    F.normalize's denominator max(|x|_2, 1e-12)."""
+    g = gen(5)
+    for shape in ((384, 16, 16, 16), (64, 6, 7, 8), (10, 3, 5, 7), (6, 1, 1, 3)):
+        feat = (torch.randn(shape, generator=g) * 2).half()
+        feat[:, 0, 0, 0] = 0
+        got = vt.similarity.voxel_norms(feat.to(gpu)).cpu()
+        want = feat.double().norm(dim=0).clamp_min(1e-12)
+        assert got.shape == want.shape and torch.allclose(got.double(), want, rtol=2e-6, atol=0), shape
+        assert float(got[0, 0, 0]) == pytest.approx(1e-12)
 
 
 # ---------------------------------------------------------------- bilateral solver (SURVEY.md 8f-1)

@@ -145,6 +145,9 @@ def main():
             vol = np.zeros((256, 256, 256), np.float32)
             ms = timeit(lambda: vt.compute_similarities(vol, feat, ann), reps=5, warm=2)
             print(f'similarity 64^3x384, A={na}: {ms:.3f} ms end-to-end  ({feat.numel() * 2 / ms / 1e6:.0f} GB/s of feature bytes, {262144 * na / ms / 1e3:.0f} Mvoxel-sim/s)')
+        fd = feat.to(dev)
+        ms = timeit(lambda: vt.similarity.voxel_norms(fd), reps=5, warm=2)
+        print(f'voxel norms 64^3x384: {ms:.3f} ms  ({feat.numel() * 2 / ms / 1e6:.0f} GB/s)')
         # BASELINE configs[4]: 1024 annotations for each of 5 classes (VITTF_SIM_MFMA=0 keeps the VALU kernel)
         ann = {f'c{i}': torch.randint(0, 256, (1024, 3), generator=g) for i in range(5)}
         ms = timeit(lambda: vt.compute_similarities(vol, feat, ann), reps=3, warm=1)

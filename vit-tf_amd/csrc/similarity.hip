@@ -96,6 +96,38 @@ __global__ __launch_bounds__(256) void voxel_norm_kernel(const unsigned short* _
   if (v0 + 1 < nvox) out[v0 + 1] = fmaxf(sqrtf(s1), 1e-12f);
 }
 
+// The same norms with the feature axis split over the workgroup's four waves and 4 voxels per thread (f % 4 == 0,
+// nvox % 4 == 0, 16-byte aligned volume): like the similarity pass, a 64^3 volume is too few voxels to keep enough loads
+// in flight with one thread per voxel pair.  Partial sums of squares meet in wave 0 as ((p0 + p1) + p2) + p3.
+__global__ __launch_bounds__(256) void voxel_norm_split_kernel(const unsigned short* __restrict__ feat, int f, int64_t nvox,
+                                                               float* __restrict__ out) {
+  __shared__ float part[3][4][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t v0 = ((int64_t)blockIdx.x * 64 + lane) * 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  const int fq = f >> 2, f0 = wave * fq;
+  if (v0 < nvox) {
+#pragma unroll 8
+    for (int ff = f0; ff < f0 + fq; ++ff) {
+      const uint2 raw = *reinterpret_cast<const uint2*>(feat + (int64_t)ff * nvox + v0);
+      const float x0 = f16bits_to_f32((unsigned short)(raw.x & 0xffff)), x1 = f16bits_to_f32((unsigned short)(raw.x >> 16));
+      const float x2 = f16bits_to_f32((unsigned short)(raw.y & 0xffff)), x3 = f16bits_to_f32((unsigned short)(raw.y >> 16));
+      s[0] = fmaf(x0, x0, s[0]); s[1] = fmaf(x1, x1, s[1]); s[2] = fmaf(x2, x2, s[2]); s[3] = fmaf(x3, x3, s[3]);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[wave - 1][j][lane] = s[j];
+  }
+  __syncthreads();
+  if (wave != 0 || v0 >= nvox) return;
+  float4 o;
+  float* op = &o.x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) op[j] = fmaxf(sqrtf(((s[j] + part[0][j][lane]) + part[1][j][lane]) + part[2][j][lane]), 1e-12f);
+  *reinterpret_cast<float4*>(out + v0) = o;
+}
+
 // ---------------------------------------------------------------- similarity
 constexpr int ACH = 16;   // annotations per pass over the volume
 constexpr int VPT = 2;    // voxels per thread (4-byte loads): 64^3 voxels -> 2048 waves, 8 per CU (4 per thread left the
@@ -347,6 +379,11 @@ extern "C" int vittf_sample_features(const void* feat, int32_t feat_is_fp16, int
 
 extern "C" int vittf_voxel_norm(const uint16_t* feat, int32_t f, int64_t nvox, float* out, void* stream) {
   if (!feat || !out || f <= 0 || nvox <= 0 || ((uintptr_t)feat & 3) != 0) return VITTF_ERR_INVALID_ARG;
+  if (f % 4 == 0 && nvox % 4 == 0 && (((uintptr_t)feat | (uintptr_t)out) & 15) == 0) {
+    hipLaunchKernelGGL(voxel_norm_split_kernel, dim3((unsigned)((nvox / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream, feat, f,
+                       nvox, out);
+    return vittf_check_launch();
+  }
   const int64_t threads = (nvox + 1) / 2;
   hipLaunchKernelGGL(voxel_norm_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat, f, nvox,
                      out);

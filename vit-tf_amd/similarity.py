@@ -59,7 +59,7 @@ def sample_features3d(feat_vol, rel_coords, mode='nearest'):
 
 
 def compute_similarities(volume, features, annotations, bilateral_solver=False, device=None, normalize=False,
-                         keep_on_device=False):
+                         keep_on_device=False, voxel_norm=None):
     """predict_ntf.py:24-101.  volume: (W, H, D) array/tensor (only its shape is used unless bilateral_solver);
     features: (F, W', H', D'); annotations: {name: (n, 3) voxel coords}.
     bilateral_solver=True: every class map is refined by the 3-D bilateral solver against the volume
@@ -68,6 +68,8 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
     (predict_ntf.py:51-55).  Classes with zero annotations are skipped.
     normalize=True: cosine similarity -- the volume is L2-normalised per voxel first, as
     compare_feat_sampling.py:45 and tests/test_vishum.py:12 do (predict_ntf.py itself does not).
+    voxel_norm: voxel_norms(features) computed earlier (an interactive session queries one volume many times);
+    implies normalize.
     keep_on_device=True: the maps stay on the GPU (for assign_labels / further kernels) instead of the reference's
     CPU tensors: at 512^3 the (256, 256, 256) uint8 maps are 17 MB per class, 2 ms of copies for a 0.3 ms query."""
     if len(annotations) == 0:
@@ -87,7 +89,12 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
     ext = torch.tensor([list(in_dims)], dtype=torch.float32)
     rel = ((coords.float() + 0.5) / ext * 2.0 - 1.0).to(dev).contiguous()
     a_total = rel.shape[0]
-    vnorm = voxel_norms(feat) if normalize else None
+    if voxel_norm is not None:
+        vnorm = torch.as_tensor(voxel_norm).to(dev, torch.float32).contiguous()
+        if vnorm.numel() != n0 * n1 * n2:
+            raise ValueError(f'voxel_norm has {vnorm.numel()} entries for {n0 * n1 * n2} voxels')
+    else:
+        vnorm = voxel_norms(feat) if normalize else None
     qf = torch.empty((a_total, f), dtype=torch.float32, device=dev)
     _lib.check(lib.vittf_sample_features(_lib.ptr(feat), 1, f, n0, n1, n2, _lib.ptr(rel), a_total,
                                          _lib.SAMPLE_MODES['bilinear'], _lib.ptr(vnorm), _lib.ptr(qf), _lib.stream_ptr()),
