@@ -21,8 +21,8 @@ AXIS_DIMS = {'z': (2, (0, 1)), 'y': (1, (0, 2)), 'x': (0, (1, 2))}
 DEFAULT_ENGINE_BATCH = 32
 # Batches of slices are independent, so consecutive batches can go round-robin onto several HIP streams (each with
 # its own workspace): the VALU/MFMA-bound attention of one batch then overlaps the HBM-bound LayerNorm / GEMM
-# epilogues of another and covers the under-filled last wave of workgroups of every launch.  Measured +4.8 % slices/s
-# with 2 lanes (r01); the default stays 1 so that per-kernel launch durations (bench.py's roofline leg, rocprof)
+# epilogues of another and covers the under-filled last wave of workgroups of every launch.  Measured +5.9 % slices/s
+# with 2 lanes (r01k: 1978 against 1867); the default stays 1 so that per-kernel launch durations (bench.py's roofline leg, rocprof)
 # are those of the kernel alone.
 STREAM_LANES = int(__import__('os').environ.get('VITTF_STREAM_LANES', '1'))
 PARTS = {'q': 0, 'k': 1, 'v': 2}
