@@ -23,6 +23,7 @@ for s in "$@"; do
     bench)    step bench 900 python bench.py --steps 2 --warmup 1 ;;
     bench64)  step bench64 600 python bench.py --steps 1 --warmup 1 --workload 64 --cpu-slices 0 ;;
     prof)     cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
+              export VITTF_BENCH_OVERLAP=0   # the profile is of the contract measurement (one lane), not of the two-lane leg
               step rocprof 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 1 --warmup 1 --workload 64 --cpu-slices 0 ;;
     *) echo "unknown step $s" ;;
   esac
