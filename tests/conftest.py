@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no libvittf.so (built artefacts are git-ignored): build it once (hipcc cross-compiles gfx950
+    without a GPU) so that the C-ABI surface tests and every -m gpu test find the in-tree library."""
+    lib = os.path.join(ROOT, 'vit-tf_amd', 'libvittf.so')
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'vit-tf_amd', 'csrc'), '-j', str(min(8, os.cpu_count() or 2))],
+                       check=True, stdout=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
