@@ -1,50 +1,86 @@
 #!/usr/bin/env python3
-"""Benchmark of the vit-tf hot path on MI355X: slices/sec of the ViT-S/8 feature-volume extraction (+ the
-16-query similarity step), BASELINE.json's metric.
+"""Benchmark of the vit-tf hot path on MI355X: slices/sec of the ViT-S/8 feature-volume extraction on a 512^3 volume
+(+ the 16-query similarity step), BASELINE.json's metric.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one synthetic volume that is already resident in HBM:
-every axis-aligned slice through ViT-S/8 (seeded synthetic weights, bf16 MFMA operands), slice-axis pooling,
-the fp16 z+y+x sum (with one RCCL all-gather per axis when N > 1), then a 16-query similarity volume and the
-label volume.  N = 1 runs BASELINE.json configs[1] (256^3 volume, 768 slices of 512 x 512); N > 1 runs
-configs[2] (512^3 CT-like volume, 1536 slices sharded over the ranks).  value = slices pushed through the
-ViT by all ranks / wall time of the K timed steps (max over ranks).
+`python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself (child processes under
+torch.distributed.run, before this process touches a GPU) and exits with their code.
 
-Extra objects on the JSON line: "roofline" for the dominant kernel (durations from HIP events recorded on the
-launch stream inside the timed region, algorithmic FLOPs from SURVEY.md 8d) and "cpu_baseline" (the oracle's
-CPU fp32 restatement of the same ViT on the host cores, rank 0 at N = 1, bounded sample).
+One "step" = one pass of the hot path over one synthetic volume that is already resident in HBM: every axis-aligned slice
+through ViT-S/8 (seeded synthetic weights, fp16 MFMA operands = the reference's GPU autocast type, the dtype whose parity
+tests assert 1e-3), slice-axis pooling, the fp16 z+y+x sum (with one RCCL all-gather per axis when N > 1), then a 16-query
+similarity volume and the label volume.  Every N runs the metric's configuration: the 512^3 CT-like volume = 1536 slices
+of 512 x 512 per step (BASELINE configs[2]; sharded over the ranks for N > 1, "scaling": "strong").  value = slices pushed
+through the ViT by all ranks / wall time of the K timed steps (max over ranks).
+
+Extra objects on the JSON line: "roofline" for the kernel with the largest share of the step (durations from HIP events
+recorded on the launch stream inside the timed region, algorithmic FLOPs from SURVEY.md 8d), "roofline_similarity" for
+the similarity accumulation kernel (HBM-bound), and "cpu_baseline" (the oracle's CPU fp32 restatement of the same ViT and
+of the reference's similarity formulation on the host cores, rank 0 at N = 1, bounded samples).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import vit_tf_amd as vt   # noqa: E402
-
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0}     # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                              # HBM3E peak, MI355X_MICROARCH.md (6.3 TB/s achievable)
 FOS = 64
+N_QUERIES = 16
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', type=str, default='512', choices=['64', '256', '512'],
+                    help="512 = the metric's configuration (default for every N); 256 / 64 = BASELINE configs[1] / [0]")
+    ap.add_argument('--dtype', type=str, default='fp16', choices=['fp16', 'bf16'],
+                    help='MFMA operand type: fp16 (default; parity tests assert 1e-3) or bf16 (2.4e-3 .. 3.9e-3)')
+    ap.add_argument('--arch', type=str, default='vits8', choices=['vits8', 'vitb8'],
+                    help="vits8 = the BASELINE metric's model; vitb8 = configs[3]'s feature extractor (D = 768), informative")
+    ap.add_argument('--engine-batch', type=int, default=32)
+    ap.add_argument('--cpu-slices', type=int, default=5, help='slices timed for the CPU baseline (0 = skip)')
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """No launcher around us and --gpus N > 1: start the N ranks as children (never a re-exec) and leave with their code."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
 
 
 def vit_flops(n_tokens, dim, depth, patch):
-    """Algorithmic FLOPs per slice: (attention, qkv/proj/K linears, MLP, patch embed)."""
-    attn = (depth - 1) * 4 * n_tokens * n_tokens * dim
-    lin = (depth - 1) * 8 * n_tokens * dim * dim + 2 * n_tokens * dim * dim
-    mlp = (depth - 1) * 16 * n_tokens * dim * dim
-    pe = 2 * (n_tokens - 1) * 3 * patch * patch * dim
-    return attn, lin, mlp, pe
+    """Algorithmic FLOPs per slice: per-kernel-class shares of F_min."""
+    nd2 = n_tokens * dim * dim
+    return {
+        'attention': (depth - 1) * 4 * n_tokens * n_tokens * dim,
+        'gemm_qkv': (depth - 1) * 6 * nd2, 'gemm_proj': (depth - 1) * 2 * nd2,
+        'gemm_fc1': (depth - 1) * 8 * nd2, 'gemm_fc2': (depth - 1) * 8 * nd2,
+        'gemm': 2 * nd2,                                     # K projection of the last block
+        'patch_embed': 2 * (n_tokens - 1) * 3 * patch * patch * dim,
+    }
 
 
-def make_workload(name):
+def make_workload(name, vt):
     """(volume fp16, label uint8, description) -- seeded, generated on the host before timing."""
     if name == '256':
         vol, label = vt.synthetic_volume('torus_filled', 256, 0.1, 0)
@@ -52,16 +88,17 @@ def make_workload(name):
                            '(N=4097) + 16-query similarity -> BASELINE configs[1]'
     if name == '512':
         vol, label = vt.ct_like_volume(512, 0)
-        return vol, label, '512^3 CT-like synthetic volume (seed 0), ViT-S/8, fos 64: 1536 slices of 512x512 (N=4097) ' \
-                           'sharded over the ranks + RCCL all-gather + 16-query similarity -> BASELINE configs[2]'
+        return vol, label, '512^3 CT-like synthetic volume (seed 0), ViT-S/8, fos 64: 1536 slices of 512x512 (N=4097) per ' \
+                           'step + 16-query similarity -> the metric\'s configuration (BASELINE configs[2])'
     if name == '64':
         vol, label = vt.synthetic_volume('torus_filled', 64, 0.1, 0)
         return vol, label, '64^3 synthetic torus volume, ViT-S/8, fos 64: 192 slices of 512x512 (N=4097) -> BASELINE configs[0]'
     raise SystemExit(f'unknown workload {name}')
 
 
-def query_voxels(label, n=16):
+def query_voxels(label, n=N_QUERIES):
     """n seeded voxel coordinates inside the labelled region (drawn from a strided sub-grid: cheap at 512^3)."""
+    import torch
     g = torch.Generator().manual_seed(0)
     step = max(1, label.shape[0] // 64)
     idx = (label[::step, ::step, ::step] > 0).nonzero() * step
@@ -69,16 +106,22 @@ def query_voxels(label, n=16):
     return {'ntf1': idx[pick]}
 
 
-def pmc_traffic(kernel_class, batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/pmc_*.json:
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads + WRITE_SIZE, separate passes).
-    The counters cannot be collected from inside this process; null when no pass is on file for this shape."""
+def kernel_source_hash(name):
+    """sha1 of a kernel source file: a committed PMC pass only describes the kernel it was measured on."""
+    with open(os.path.join(ROOT, 'vit-tf_amd', 'csrc', name), 'rb') as f:
+        return hashlib.sha1(f.read()).hexdigest()
+
+
+def pmc_traffic(kernel_class, batch, source):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC pass (profiles/pmc_*.json: FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950 wide reads + WRITE_SIZE, separate passes).  The counters cannot be
+    collected from inside this process; null when no pass is on file for this shape AND this very kernel source."""
     path = os.path.join(ROOT, 'profiles', f'pmc_{kernel_class}.json')
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if rec.get('batch') != batch:
+    if rec.get('batch') != batch or rec.get('source_sha1') != kernel_source_hash(source):
         return None
     return rec.get('hbm_bytes_per_launch')
 
@@ -96,39 +139,52 @@ def host_cores():
     return max(1, min(n, int(os.environ.get('VITTF_CPU_THREADS', '16'))))
 
 
-def cpu_baseline(sd, vol, n_slices, im_sz, arch='vits8'):
-    """The oracle (CPU restatement of the reference path) on the host cores: batch-1 slice loop, fp32."""
-    from oracle import dino_vit, feature_volume as ofv
+def cpu_baseline(sd, vol, n_slices, im_sz, arch, feats_cpu, ann, vol_shape):
+    """The oracle (CPU restatement of the reference path) on the host cores: batch-1 slice loop in fp32, and the
+    reference's similarity formulation (einsum + where / pow / mean + quantise, predict_ntf.py:65, 71-72, 98-100)."""
+    import torch
+    from oracle import dino_vit, feature_volume as ofv, similarity as osim
     cores = host_cores()
     torch.set_num_threads(cores)
     model = dino_vit.build_vit(arch, sd)
-    imgs = ofv.normalized_slices(vol.float(), 'z')
-    pick = [imgs.shape[0] // 2 + i for i in range(n_slices + 1)]
+    # the z-slices around the middle of the volume, normalised exactly as the whole volume would be (global min / max)
+    mid = vol.shape[2] // 2
+    sub = vol[:, :, mid:mid + n_slices + 1].float()
+    lo, hi = float(vol.float().min()), float(vol.float().max())
+    imgs = ofv.normalized_slices(sub, 'z', minmax=(lo, hi))
     times = []
     with torch.no_grad():
-        for i, s in enumerate(pick):
+        for i in range(imgs.shape[0]):
             t0 = time.perf_counter()
-            x = torch.nn.functional.interpolate(imgs[s:s + 1], size=(im_sz[0], im_sz[1]), mode='nearest')
+            x = torch.nn.functional.interpolate(imgs[i:i + 1], size=(im_sz[0], im_sz[1]), mode='nearest')
             ofv.k_tokens(model, x).half()
             if i > 0:
                 times.append(time.perf_counter() - t0)
-    return {'value': round(len(times) / sum(times), 4), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{len(times)} z-slices of the same volume at {im_sz[0]}x{im_sz[1]} (N=4097), batch 1, fp32 torch CPU, '
-                      f'after 1 warm-up slice; the oracle runs the K projection of block 12 only, like the GPU path'}
+    out = {'value': round(len(times) / sum(times), 4), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{len(times)} z-slices of the same volume at {im_sz[0]}x{im_sz[1]} (N=4097), batch 1, fp32 torch CPU, '
+                     f'after 1 warm-up slice; the oracle runs the K projection of block 12 only, like the GPU path'}
+    # similarity: the full 64^3 x 384 feature volume, A = 16, the reference's own formulation
+    f32 = feats_cpu.float()
+    osim.similarity_maps(vol_shape, f32, ann)                       # warm-up
+    reps, t0 = 3, time.perf_counter()
+    for _ in range(reps):
+        osim.similarity_maps(vol_shape, f32, ann)
+    dt = (time.perf_counter() - t0) / reps
+    nvox = f32[0].numel()
+    out['similarity'] = {'ms': round(dt * 1e3, 2), 'mvoxel_sim_per_s': round(nvox * N_QUERIES / 1e6 / dt, 1), 'queries': N_QUERIES,
+                         'cores': cores, 'kind': 'port',
+                         'sample': f'full {tuple(f32.shape)} fp32 feature volume, {N_QUERIES} queries, einsum + where/pow/mean + '
+                                   f'quantise + nearest resize (oracle/similarity.py = predict_ntf.py:52-72, 95-100), mean of {reps}'}
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', type=str, default=None, choices=['64', '256', '512'])
-    ap.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'fp16'])
-    ap.add_argument('--arch', type=str, default='vits8', choices=['vits8', 'vitb8'],
-                    help="vits8 = the BASELINE metric's model; vitb8 = configs[3]'s feature extractor (D = 768), informative")
-    ap.add_argument('--engine-batch', type=int, default=32)
-    ap.add_argument('--cpu-slices', type=int, default=5, help='slices timed for the CPU baseline (0 = skip)')
-    args = ap.parse_args()
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                       # before anything touches a GPU
+
+    import torch
+    import vit_tf_amd as vt
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -138,6 +194,7 @@ def main():
     local = local % max(1, torch.cuda.device_count())     # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    backend = None
     if world > 1:
         backend = os.environ.get('VITTF_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm
         if backend == 'nccl':
@@ -146,9 +203,15 @@ def main():
             torch.distributed.init_process_group(backend)
     barrier = (lambda: torch.distributed.barrier()) if world > 1 else (lambda: None)
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
     torch.set_num_threads(max(1, host_cores() // max(1, min(world, 8))))   # host-side generation only
-    wl = args.workload or ('256' if world == 1 else '512')
-    vol, label, desc = make_workload(wl)
+    vol, label, desc = make_workload(args.workload, vt)
     desc = desc.replace('ViT-S/8', 'ViT-B/8 (D = 768)') if args.arch == 'vitb8' else desc
     sd = vt.synthetic_state_dict(args.arch, 0)
     model = vt.HipViT(sd, args.arch, args.dtype, device=dev)
@@ -176,7 +239,8 @@ def main():
     barrier()
     # HIP events around the launches of the dominant kernel only (attention, ~50 % of the kernel time): bracketing every
     # launch costs 2-3 % of the throughput.  The other classes are timed in one extra, untimed step below.
-    vt._lib.profiler_enable(True, classes=None if os.environ.get('VITTF_BENCH_FULLPROF') == '1' else ['attention'])
+    fullprof = os.environ.get('VITTF_BENCH_FULLPROF') == '1'
+    vt._lib.profiler_enable(True, classes=None if fullprof else ['attention'])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -185,18 +249,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = vt._lib.profiler_collect()
-    vt._lib.profiler_enable(True)                       # all classes, one step outside the timed region
-    step()
-    torch.cuda.synchronize()
-    prof_all = vt._lib.profiler_collect()
+    if not fullprof:
+        vt._lib.profiler_enable(True)                       # all classes, one step outside the timed region
+        step()
+        torch.cuda.synchronize()
+        prof_all = vt._lib.profiler_collect()
+        for k, (ms, n) in prof_all.items():
+            if k != 'attention':
+                prof[k] = (ms * args.steps, n * args.steps)  # scaled to the timed steps (same launches every step)
     vt._lib.profiler_enable(False)
-    for k, (ms, n) in prof_all.items():
-        if k != 'attention':
-            prof[k] = (ms * args.steps, n * args.steps)  # scaled to the timed steps (same launches every step)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     # the same K steps once more with two batches in flight on two streams (outside the timed region, informative): the
     # HBM-bound GEMM epilogues of one batch run under the attention of another; per-kernel durations stretch then, which
@@ -217,70 +279,97 @@ def main():
             el2 = time.perf_counter() - t1
         finally:
             vt.extract.STREAM_LANES = lanes_before
-        if world > 1:
-            t = torch.tensor([el2], dtype=torch.float64, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            el2 = float(t.item())
+        el2 = max_over_ranks(el2)
         overlap = {'stream_lanes': 2, 'value': round(args.steps * total_slices / el2, 2), 'unit': 'slices/s',
                    'ms_per_step': round(el2 / args.steps * 1e3, 2),
                    'note': 'VITTF_STREAM_LANES=2, same steps, measured after the timed region; not the contract value'}
 
-    # similarity leg alone (outside the timed region): Mvoxel-sim/s = Nvox * A / time
-    n_rep = 5
+    # similarity leg alone (outside the timed region): Mvoxel-sim/s = Nvox * A / time; HIP events around the accumulation
+    # kernel (class 'similarity') give its HBM roofline
+    n_rep = 20
+    vt.compute_similarities(vol, feats, ann)
     torch.cuda.synchronize()
     ts = time.perf_counter()
     for _ in range(n_rep):
         vt.compute_similarities(vol, feats, ann)
     torch.cuda.synchronize()
     sim_ms = (time.perf_counter() - ts) / n_rep * 1e3
+    vt._lib.profiler_enable(True, classes=['similarity'])
     ts = time.perf_counter()
     for _ in range(n_rep):                               # the same query with the maps left on the GPU (no host copies)
         vt.compute_similarities(vol, feats, ann, keep_on_device=True)
     torch.cuda.synchronize()
     sim_dev_ms = (time.perf_counter() - ts) / n_rep * 1e3
+    sim_k_ms, sim_k_n = vt._lib.profiler_collect()['similarity']
+    vt._lib.profiler_enable(False)
     nvox = feat_out[0] * feat_out[1] * feat_out[2]
+    n_classes = len(ann)
+    sim_bytes = nvox * (2 * dim + 4 * n_classes)             # fp16 feature row read once + fp32 class maps written
+    sim_avg_ms = sim_k_ms / max(1, sim_k_n)
+    sim_gbs = sim_bytes / (sim_avg_ms * 1e-3) / 1e9 if sim_avg_ms > 0 else 0.0
+    roofline_sim = {
+        'bound': 'hbm', 'achieved': round(sim_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+        'frac': round(sim_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc_traffic('similarity', N_QUERIES, 'similarity.hip'),
+        'kernel': 'sim_accumulate_split<fp16>', 'launches': int(sim_k_n), 'avg_launch_ms': round(sim_avg_ms, 5),
+        'bytes_per_launch': sim_bytes,
+        'note': f'algorithmic bytes = Nvox * (2 D + 4 C) = {nvox} * (2*{dim} + 4*{n_classes}); a repeated query finds the '
+                f'{nvox * 2 * dim / 1e6:.0f} MB volume in the 256 MB Infinity Cache',
+    }
 
-    attn_f, lin_f, mlp_f, pe_f = vit_flops(n_tokens, dim, depth, patch)
+    flop_slice = vit_flops(n_tokens, dim, depth, patch)
     slices_done = my_slices * args.steps
-    if prof['mlp'][1] == 0:          # unfused MLP: its two GEMMs are counted in the gemm class
-        lin_f, mlp_f = lin_f + mlp_f, 0
-    flops = {'attention': attn_f * slices_done, 'gemm': lin_f * slices_done, 'mlp': mlp_f * slices_done}
-    dom = 'attention'     # the single kernel with the largest share of the step (the gemm class is four different kernels)
+    if prof['mlp'][1] > 0:          # fused MLP: fc1 + fc2 in one kernel
+        flop_slice['mlp'] = flop_slice.pop('gemm_fc1') + flop_slice.pop('gemm_fc2')
+    flops = {k: v * slices_done for k, v in flop_slice.items()}
+    kernels = {'attention': f'attn_kernel<{args.dtype}>', 'gemm_qkv': f'gemm_ws_kernel<{args.dtype}, qkv>',
+               'gemm_fc1': f'gemm_ws_kernel<{args.dtype}, fc1+gelu>', 'gemm_proj': f'gemm_rows_kernel<{args.dtype}, proj+ln>',
+               'gemm_fc2': f'gemm_rows_kernel<{args.dtype}, fc2+ln>', 'gemm': f'gemm_kernel<{args.dtype}, kfeat>',
+               'mlp': f'mlp_kernel<{args.dtype}>', 'patch_embed': 'patch_embed_kernel', 'layernorm': 'layernorm_kernel'}
+    # the kernel with the largest share of the step
+    dom = max((k for k in prof if k in flops), key=lambda k: prof[k][0])
     dom_ms, dom_launches = prof[dom]
     achieved = flops[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.dtype]
+    vit_ms = sum(v[0] for k, v in prof.items() if k != 'similarity')
     roofline = {
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-        'traffic': pmc_traffic(dom, args.engine_batch if my_slices >= args.engine_batch else my_slices) if args.arch == 'vits8' else None,
-        'kernel': {'attention': f'attn_kernel<{args.dtype}>', 'gemm': f'gemm_kernel<{args.dtype}, *>',
-                   'mlp': f'mlp_kernel<{args.dtype}>'}[dom],
+        'traffic': pmc_traffic(dom, args.engine_batch if my_slices >= args.engine_batch else my_slices, 'attention.hip')
+        if (args.arch == 'vits8' and dom == 'attention') else None,
+        'kernel': kernels[dom],
         'launches': int(dom_launches), 'avg_launch_ms': round(dom_ms / max(1, dom_launches), 4),
         'flop_per_launch': flops[dom] / max(1, dom_launches),
-        'kernel_ms_rank0': {k: round(v[0], 2) for k, v in prof.items()},
+        'kernel_ms_rank0': {k: round(v[0], 2) for k, v in prof.items() if k != 'similarity'},
+        'kernel_tflops_rank0': {k: round(flops[k] / (prof[k][0] * 1e-3) / 1e12, 1) for k in flops if prof[k][0] > 0},
         'kernel_ms_note': 'attention: events inside the timed steps; other classes: one extra untimed step x steps',
-        'whole_vit_tflops': round((attn_f + lin_f + mlp_f + pe_f) * slices_done / (sum(v[0] for v in prof.values()) * 1e-3) / 1e12, 2)
-        if sum(v[0] for v in prof.values()) > 0 else 0.0,
+        'whole_vit_tflops': round(sum(flops.values()) / (vit_ms * 1e-3) / 1e12, 2) if vit_ms > 0 else 0.0,
     }
 
     if rank == 0:
         out = {
-            'metric': f'slices/sec ({"ViT-S/8" if args.arch == "vits8" else "ViT-B/8"}, feature volume + 16-query similarity)', 'value': round(args.steps * total_slices / elapsed, 2),
+            'metric': f'slices/sec ({"ViT-S/8" if args.arch == "vits8" else "ViT-B/8"}, {args.workload}^3 vol: feature volume + '
+                      f'{N_QUERIES}-query similarity)',
+            'value': round(args.steps * total_slices / elapsed, 2),
             'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
             'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'rccl_ranks': torch.distributed.get_world_size() if world > 1 else 1,
             'config': {'workload': desc, 'volume': list(dvol.shape), 'slices_per_step': total_slices,
                        'image': [im_sz[0], im_sz[1]], 'tokens': n_tokens, 'feature_volume': [dim, *feat_out],
                        'engine_batch': args.engine_batch, 'weights': f'seeded synthetic {args.arch} (seed 0)',
-                       'parallelism': f'slices sharded over {world} rank(s), one all-gather per axis' if world > 1 else 'single GPU'},
+                       'parallelism': f'slices sharded over {world} rank(s), one all-gather per axis' if world > 1 else 'single GPU',
+                       'dist_backend': backend},
             'roofline': roofline,
-            'similarity': {'ms': round(sim_ms, 3), 'queries': 16, 'mvoxel_sim_per_s': round(nvox * 16 / 1e6 / (sim_ms * 1e-3), 1),
+            'roofline_similarity': roofline_sim,
+            'similarity': {'ms': round(sim_ms, 3), 'queries': N_QUERIES,
+                           'mvoxel_sim_per_s': round(nvox * N_QUERIES / 1e6 / (sim_ms * 1e-3), 1),
                            'mvoxel_per_s': round(nvox / 1e6 / (sim_ms * 1e-3), 1),
+                           'queries_per_s': round(N_QUERIES / (sim_ms * 1e-3), 1),
                            'ms_maps_on_device': round(sim_dev_ms, 3),
                            'note': 'ms: the reference API (uint8 maps returned as CPU tensors); ms_maps_on_device: keep_on_device=True'},
         }
         out['two_lane_overlap'] = overlap
         if world == 1 and args.cpu_slices > 0:
-            out['cpu_baseline'] = cpu_baseline(sd, vol, args.cpu_slices, im_sz, args.arch)
+            out['cpu_baseline'] = cpu_baseline(sd, vol, args.cpu_slices, im_sz, args.arch, feats.cpu(), ann, tuple(dvol.shape))
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)

@@ -32,11 +32,12 @@ def evaluate(data_dir, label_fn, label_names):
     labels_orig = torch.as_tensor(np.load(label_fn, allow_pickle=True)[()])
     preds = {k: torch.as_tensor(v) for k, v in np.load(data_dir / 'predictions.npy', allow_pickle=True)[()].items()}
     results = {}
+    labels_dev = vt.samplers.device_labels(labels_orig)          # one upload, every class resized from it
     for name, key in zip(label_names, sorted(preds.keys())):
         p = preds[key]
-        mask = (labels_orig == label2idx[name]).to(torch.uint8)[None, None]
-        target = F.interpolate(mask, p.shape[-3:], mode='nearest').reshape(-1)
-        acc, prec, rec, f1, iou, cm = binary_scores(target.numpy(), p.reshape(-1).numpy())
+        # (:63) F.interpolate((labels == idx)[None, None], p.shape, mode='nearest'): mask + resize in one kernel
+        target = vt.scores.resize_nearest_u8(labels_dev, p.shape[-3:], equals=label2idx[name], keep_on_device=True)
+        acc, prec, rec, f1, iou, cm = binary_scores(target.reshape(-1), p.reshape(-1).numpy())
         results[name] = {'accuracy': acc, 'precision': prec, 'recall': rec, 'f1': f1, 'iou': iou,
                          'confusion_matrix': cm, 'annotation_time': metadata[key]['time'],
                          'num_annotations': metadata[key]['num_annotations']}

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITTF_ABI_VERSION 1
+#define VITTF_ABI_VERSION 2
 
 typedef enum vittf_status {
   VITTF_OK = 0,
@@ -125,15 +125,22 @@ int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit_weights* w
                          const vittf_slice_view* view, int32_t slice0, int32_t batch, int32_t qkv_part,
                          uint16_t* k_out, void* ws, size_t ws_bytes, void* stream);
 
-/* Optional timing of the launches inside vittf_vit_k_features, by kernel class, with HIP events recorded on
+/* Optional timing of the launches inside vittf_vit_k_features and vittf_similarity, by kernel class, with HIP events recorded on
  * the caller's stream (what bench.py's roofline leg reads).  Process-global, off by default, not thread-safe:
  * the one exception to "no global mutable state".  enable(mask) clears earlier records and starts recording the
  * classes whose bit (1 << vittf_kernel_class) is set (-1: all; two event records per launch cost ~2-3 % of the
  * throughput when every launch is bracketed, so bench.py times with the dominant class only), enable(0) stops; collect() waits for the recorded events and returns, per class, the summed launch
  * durations in ms and the launch counts (arrays of VITTF_KERNEL_CLASSES entries, [host]). */
 typedef enum vittf_kernel_class {
-  VITTF_KERNEL_PATCH_EMBED = 0, VITTF_KERNEL_LAYERNORM = 1, VITTF_KERNEL_GEMM = 2, VITTF_KERNEL_ATTENTION = 3,
-  VITTF_KERNEL_MLP = 4, VITTF_KERNEL_CLASSES = 5
+  VITTF_KERNEL_PATCH_EMBED = 0, VITTF_KERNEL_LAYERNORM = 1,
+  VITTF_KERNEL_GEMM = 2,        /* linears without a class of their own: the K-feature projection */
+  VITTF_KERNEL_ATTENTION = 3, VITTF_KERNEL_MLP = 4,
+  VITTF_KERNEL_GEMM_QKV = 5,    /* attn.qkv (+ q pre-scale) */
+  VITTF_KERNEL_GEMM_PROJ = 6,   /* attn.proj + residual (+ norm2) */
+  VITTF_KERNEL_GEMM_FC1 = 7,    /* mlp.fc1 + GELU */
+  VITTF_KERNEL_GEMM_FC2 = 8,    /* mlp.fc2 + residual (+ the next norm1) */
+  VITTF_KERNEL_SIMILARITY = 9,  /* the voxel x query accumulation kernel(s) inside vittf_similarity / _maps_f32 */
+  VITTF_KERNEL_CLASSES = 10
 } vittf_kernel_class;
 int vittf_profiler_enable(int32_t class_mask);
 int vittf_profiler_collect(double* ms_per_class, int64_t* launches_per_class);
@@ -288,6 +295,16 @@ int vittf_surface_shell(const uint8_t* labels, int32_t n0, int32_t n1, int32_t n
  * value >= classes in either volume.  counts: int64 [classes * classes + 1] (device, overwritten); classes <= 16. */
 int vittf_confusion_matrix(const uint8_t* target, const uint8_t* pred, int64_t n, int32_t classes, int64_t* counts,
                            void* stream);
+
+/* F.interpolate(mode='nearest') of a uint8 volume (n0, n1, n2) -> (o0, o1, o2): src index = min(floor(dst * (float)in /
+ * out), in - 1) per dim.  equals < 0: plain resize -- the label up-sample of predict_ntf.py:217-218; equals = c in 0..255:
+ * the resized class mask (src == c) as 0/1 -- evaluate_similarities.py:63 without materialising the full-size mask. */
+int vittf_resize_nearest_u8(const uint8_t* src, int32_t n0, int32_t n1, int32_t n2, uint8_t* dst, int32_t o0, int32_t o1,
+                            int32_t o2, int32_t equals, void* stream);
+
+/* dst fp32 [n] = src fp16 [n] (exact): volumes are stored as fp16 (create_synthetic_volumes.py:44-46) and uploaded as
+ * such; the vol.float() of infer.py:137 / the astype(np.float32) of infer.py:230-232 happens in HBM.  16-byte aligned. */
+int vittf_widen_f16(const uint16_t* src, int64_t n, float* dst, void* stream);
 
 /* ---- 3-D bilateral solver post-process (bilateral_solver3d.py, predict_ntf.py:73-96) ---------- */
 typedef struct vittf_bilateral_params {

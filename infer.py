@@ -11,7 +11,7 @@ Differences a caller can observe:
     checkpoint cache) or from seeded synthetic weights (``--synthetic-weights SEED``); nothing is
     fetched from the network (the reference calls torch.hub.load, :42-43)
   * ``--batch-size`` no longer changes memory behaviour: slices are independent and the engine picks its
-    own batch (results do not depend on it); ``--engine-dtype`` selects bf16 (default) or fp16 MFMA operands
+    own batch (results do not depend on it); ``--engine-dtype`` selects fp16 (default, the reference's autocast type :309) or bf16 MFMA operands
   * launched under torchrun, the slices of each axis are sharded over the ranks and reassembled with one
     RCCL all-gather per axis; rank 0 writes the file
 """
@@ -61,7 +61,7 @@ def norm_mean_std(t, mu=0, std=1):
 
 
 # ---------------------------------------------------------------------------- model (:42-46, :239-264)
-_MODEL_OPTS = {'weights': None, 'synthetic_seed': None, 'dtype': 'bf16'}
+_MODEL_OPTS = {'weights': None, 'synthetic_seed': None, 'dtype': 'fp16'}
 
 
 def get_dino_model(name):
@@ -155,7 +155,9 @@ def compute_qkv(vol, model, patch_size, im_sizes, pool_fn=_noop, batch_size=1, s
 
 
 # ---------------------------------------------------------------------------- I/O (:212-237, :266-288)
-def load_data(data_path):
+def load_data(data_path, keep_dtype=False):
+    """(:212-237).  keep_dtype=True (used by main()): a .npy volume stays in its stored type instead of fp32, so that an
+    fp16 file is uploaded as 2-byte values and widened on the GPU (vittf_widen_f16) -- same fp32 values."""
     data_path = Path(data_path)
     if not data_path.exists():
         print(f'Invalid argument for --data-path (File does not exist): {data_path}')
@@ -167,7 +169,8 @@ def load_data(data_path):
     elif data_path.suffix == '.npy':
         data = np.load(data_path, allow_pickle=True)
         arr = data[()]['vol'] if data.dtype == object else data
-        vol = torch.from_numpy(np.asarray(arr).astype(np.float32))
+        arr = np.asarray(arr)
+        vol = torch.from_numpy(arr if keep_dtype and arr.dtype == np.float16 else arr.astype(np.float32))
     else:
         print(f'Unsupported file extension: {data_path.suffix}')
         sys.exit(1)
@@ -216,6 +219,27 @@ def _init_distributed():
     return torch.distributed.get_rank(), world
 
 
+def _agree_on_output_path(args, rank, world):
+    """handle_output_path on rank 0; its verdict (0 or the exit code) is broadcast so that every rank leaves together
+    instead of the others hanging in the first collective until the RCCL timeout."""
+    cache_path, code = None, 0
+    if rank == 0:
+        try:
+            cache_path = handle_output_path(args)
+        except SystemExit as e:
+            code = int(e.code) if isinstance(e.code, int) else 1
+    if world > 1:
+        dev = torch.device('cuda', torch.cuda.current_device()) if torch.distributed.get_backend() == 'nccl' else 'cpu'
+        verdict = torch.tensor([code], dtype=torch.int32, device=dev)
+        torch.distributed.broadcast(verdict, src=0)
+        code = int(verdict.item())
+    if code != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        sys.exit(code)
+    return cache_path
+
+
 def main(argv=None):
     from argparse import ArgumentParser
     dino_archs = ['vits16', 'vits8', 'vitb16', 'vitb8']
@@ -235,7 +259,8 @@ def main(argv=None):
     # additions of the MI355X build
     parser.add_argument('--weights', type=str, default=None, help='Local DINO state dict (.pth)')
     parser.add_argument('--synthetic-weights', type=int, default=None, metavar='SEED', help='Use seeded synthetic weights')
-    parser.add_argument('--engine-dtype', type=str, choices=['bf16', 'fp16'], default='bf16', help='MFMA operand type')
+    parser.add_argument('--engine-dtype', type=str, choices=['fp16', 'bf16'], default='fp16',
+                        help='MFMA operand type (fp16 = the reference GPU autocast type, 1e-3 parity; bf16 opt-in)')
     args = parser.parse_args(argv)
 
     if args.cpu:
@@ -244,9 +269,9 @@ def main(argv=None):
     _MODEL_OPTS.update(weights=args.weights, synthetic_seed=args.synthetic_weights, dtype=args.engine_dtype)
     dino_model, dino_model_fn, patch_size = load_model(args)
     rank, world = _init_distributed()
-    cache_path = handle_output_path(args) if rank == 0 else None
+    cache_path = _agree_on_output_path(args, rank, world)
 
-    vol = load_data(args.data_path)
+    vol = load_data(args.data_path, keep_dtype=True)
     im_sz, feat_out_sz = vt.sizing(tuple(vol.shape), args.feature_output_size, patch_size)
     print(f'Input image size: {im_sz}')
     model = dino_model_fn(dino_model)

@@ -45,15 +45,16 @@ def axis_image_size(im_sz, axis):
     return im_sz[a], im_sz[b]
 
 
-def normalized_slices(vol, axis):
+def normalized_slices(vol, axis, minmax=None):
     """(S, 3, rows, cols) fp32: global min-max to [0, 1], then per-channel ImageNet mean/std.
 
     infer.py:137, 154-155 (``normalize`` is torchvision's (x - mean[c]) / std[c]).
+    ``minmax``: (lo, hi) of the WHOLE volume when ``vol`` is only a slab of it (a few slices of a 512^3 volume).
     """
     vol = vol.float().squeeze()
     sl, (a, b) = AXIS_DIMS[axis]
     img = vol.permute(sl, a, b)                       # (S, rows, cols)
-    lo, hi = vol.min(), vol.max()
+    lo, hi = (vol.min(), vol.max()) if minmax is None else minmax
     img = (img - lo) / (hi - lo)
     mean = torch.tensor(IN_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(IN_STD).view(1, 3, 1, 1)

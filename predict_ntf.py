@@ -126,7 +126,7 @@ def main(argv=None):
     pred = assign_labels(similarities)
     np.save(d / f'ntf_pred{tag}.npy', pred)
     if tuple(pred.shape[-3:]) != tuple(volume.shape[-3:]):
-        pred = F.interpolate(make_5d(torch.as_tensor(pred)), tuple(volume.shape[-3:]), mode='nearest').squeeze().numpy()
+        pred = vt.scores.resize_nearest_u8(pred, tuple(volume.shape[-3:]))       # (:217-218) nearest up-sample, on the GPU
     print('Pred:', pred.shape, pred.min(), pred.max())
     print('NTF fit time:', t1 - t0)
     print('NTF predict time:', t2 - t1)

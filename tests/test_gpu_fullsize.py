@@ -1,0 +1,178 @@
+"""GPU: BASELINE.json's configurations at FULL size through the product's entry points.
+
+  configs[1]  256^3 volume -> 768 slices of 512 x 512 (2x nearest up-sampling), ViT-S/8
+  configs[2]  512^3 CT-like volume -> 1536 slices of 512 x 512, ViT-S/8          (the metric's configuration)
+  configs[4]  512^3 volume, 5 x 1024 annotations (matrix-core similarity) + 3-D bilateral solver -> 256^3 maps
+
+The CPU oracle cannot run a whole volume (a 512^3 extraction is > 1 h on the host cores), so whole volumes are held to
+size-independent properties -- every value finite, bits independent of the engine batch, the z -> y -> x fp16 sum of the
+three pooled axes reproducing the volume bit for bit -- and ONE pooling window per axis is compared with the oracle run
+on just the 4 / 8 slices that window averages (same global min / max), at the operand type whose bound is the 1e-3 of
+BASELINE.json's north_star (fp16: the engine's default and the reference's own GPU autocast type, infer.py:309).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import vit_tf_amd as vt
+from oracle import dino_vit, feature_volume as ofv, similarity as osim
+from helpers import rel_fro
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3                      # relative Frobenius error of fp16-operand features against the fp32 CPU path
+
+
+@pytest.fixture(scope='module')
+def vits8(gpu):
+    sd = vt.synthetic_state_dict('vits8', 0)
+    return sd, vt.HipViT(sd, 'vits8', 'fp16', device=gpu)
+
+
+@pytest.fixture(scope='module')
+def oracle_vits8(vits8):
+    torch.set_num_threads(min(16, len(__import__('os').sched_getaffinity(0))))
+    return dino_vit.build_vit('vits8', vits8[0])
+
+
+def _oracle_window(oracle, vol, axis, lo, hi, minmax, im_sz):
+    """fp16 pooled features (D, f0, f1) of the window that averages slices [lo, hi) of `axis`: the oracle on those slices
+    only, AdaptiveAvgPool3d's own fp16 arithmetic for the mean (infer.py:329)."""
+    sl, (a, b) = ofv.AXIS_DIMS[axis]
+    sub = vol.narrow(sl, lo, hi - lo).float()
+    imgs = ofv.normalized_slices(sub, axis, minmax=minmax)
+    rows, cols = ofv.axis_image_size(im_sz, axis)
+    ks = []
+    with torch.no_grad():
+        for i in range(imgs.shape[0]):
+            x = F.interpolate(imgs[i:i + 1], size=(rows, cols), mode='nearest')
+            ks.append(ofv.k_tokens(oracle, x).half()[0, 1:])          # hook -> fp16, CLS dropped
+    k = torch.stack(ks).view(len(ks), rows // 8, cols // 8, -1)      # (n, f0, f1, D)
+    return ofv.adaptive_pool(k.permute(3, 1, 2, 0).contiguous(), (rows // 8, cols // 8, 1))[..., 0]
+
+
+def _whole_volume_checks(gpu, vits8, oracle, vol, windows):
+    sd, model = vits8
+    dvol = vt.DeviceVolume(vol, gpu)
+    im_sz, feat_out = vt.sizing(dvol.shape, 64, 8)
+    assert im_sz == (512, 512, 512) and feat_out == (64, 64, 64)
+    feats = vt.feature_volume(None, model, 64, 'all', 32, dvol=dvol)
+    assert feats.shape == (384, 64, 64, 64) and feats.dtype == torch.float16
+    assert bool(torch.isfinite(feats).all())
+    again = vt.feature_volume(None, model, 64, 'all', 31, dvol=dvol)        # another batching of the same slices
+    assert torch.equal(feats, again), 'bits depend on the engine batch'
+    del again
+    pooled = {ax: vt.pooled_axis(None, model, ax, im_sz, feat_out, 32, dvol=dvol) for ax in 'zyx'}
+    total = (pooled['z'] + pooled['y']) + pooled['x']                        # fp16 adds, one rounding each (infer.py:330-332)
+    assert torch.equal(total, feats), 'z -> y -> x fp16 sum of the pooled axes does not reproduce the volume'
+    lo_hi = (float(dvol.minmax[0]), float(dvol.minmax[1]))
+    assert lo_hi == (float(vol.float().min()), float(vol.float().max()))
+    errs = {}
+    for ax, w in windows.items():
+        sl = ofv.AXIS_DIMS[ax][0]
+        s_lo, s_hi = vt.extract.window_bounds(w, dvol.shape[sl], feat_out[sl])
+        ref = _oracle_window(oracle, vol, ax, s_lo, s_hi, lo_hi, im_sz)
+        got = pooled[ax].select(1 + sl, w).cpu()
+        assert got.shape == ref.shape == (384, 64, 64)
+        errs[ax] = rel_fro(got, ref)
+        print(f'{tuple(dvol.shape)} axis {ax} window {w} = slices [{s_lo}, {s_hi}): rel fro {errs[ax]:.2e} vs the CPU oracle')
+    assert max(errs.values()) <= TOL, errs
+    return feats
+
+
+def test_config1_256_whole_volume(gpu, vits8, oracle_vits8):
+    """BASELINE configs[1]: every slice of the 256^3 torus volume (2x nearest up-sampling to 512 x 512)."""
+    vol, _ = vt.synthetic_volume('torus_filled', 256, 0.1, 0)
+    _whole_volume_checks(gpu, vits8, oracle_vits8, vol, {'z': 31, 'y': 40, 'x': 22})
+
+
+@pytest.fixture(scope='module')
+def ct512():
+    return vt.ct_like_volume(512, 0)
+
+
+@pytest.fixture(scope='module')
+def feats512(gpu, vits8, oracle_vits8, ct512):
+    """BASELINE configs[2] on one GPU (the metric's configuration): the 512^3 CT-like volume, 1536 slices, no up-sampling
+    (537 MB resident volume, 1.6 GB of K features per axis).  Checked once, reused by the configs[4] tests below."""
+    return _whole_volume_checks(gpu, vits8, oracle_vits8, ct512[0], {'z': 37, 'y': 11, 'x': 50})
+
+
+def test_config2_512_whole_volume(feats512):
+    assert feats512.shape == (384, 64, 64, 64)
+
+
+def _annotations_5x1024(label):
+    """configs[4]: 1024 annotations for each of 5 classes (the evaluate_similarities 1024 preset: sample_both = 512
+    uniform + 512 surface per class; the three label classes of the CT-like volume + two sub-regions as classes 4, 5)."""
+    torch.manual_seed(0)
+    dev_lab = vt.samplers.device_labels(label)
+    ann = {}
+    for i in (1, 2, 3):
+        ann[f'ntf{i}'] = vt.samplers.sample_both(dev_lab, 1024, thin_to_reasonable=True, class_id=i).cpu()
+    g = torch.Generator().manual_seed(1)
+    for i, (cls, lo) in enumerate(((1, 0), (2, 256)), start=4):               # one half of classes 1 / 2 along dim 0
+        idx = (label[lo:lo + 256:2, ::2, ::2] == cls).nonzero() * 2
+        idx[:, 0] += lo
+        ann[f'ntf{i}'] = idx[torch.randperm(idx.shape[0], generator=g)[:1024]]
+    assert all(v.shape == (1024, 3) for v in ann.values())
+    return ann
+
+
+@pytest.fixture(scope='module')
+def sims512(gpu, feats512, ct512):
+    """5 x 1024 queries against the normalised 64^3 x 384 feature volume of the 512^3 input: GPU maps (matrix-core
+    similarity kernel) and oracle maps, 256^3 uint8 each."""
+    vol, label = ct512
+    ann = _annotations_5x1024(label)
+    feat = F.normalize(feats512.float(), dim=0).half()                          # compare_feat_sampling.py:45
+    got = vt.compute_similarities(vol, feat, ann)
+    ref = osim.similarity_maps(tuple(vol.shape), feat.float().cpu(), ann)
+    return ann, feat, got, ref
+
+
+def test_config4_1024_queries_similarity(sims512):
+    ann, _, got, ref = sims512
+    for k in ann:
+        assert got[k].shape == (256, 256, 256) and got[k].dtype == torch.uint8
+        assert int(ref[k].max()) == 255 or int(ref[k].max()) >= 250
+        d = (got[k].int() - ref[k].int()).abs()
+        d = torch.minimum(d, 256 - d)
+        frac = float((d > 0).float().mean())
+        print(f'{k}: {int((d > 0).sum())} of {d.numel()} voxels differ by 1 LSB ({frac:.2e}), max |diff| {int(d.max())}')
+        assert int(d.max()) <= 1 and frac <= 1e-3, k
+
+
+def test_config4_labels_from_gpu_maps_vs_oracle_maps(sims512):
+    """Label volume (predict_ntf.py:203-215) assigned from the GPU maps against the one assigned from the ORACLE's maps.
+    The label kernel itself is bit-exact on equal maps (test_labels_bit_exact_random); the maps differ by +-1 LSB on
+    isolated voxels (fp32 summation order of 384-term dot products, two different machines), and such a voxel changes
+    its label only when it sits exactly on a class threshold or on a tie between two classes."""
+    ann, _, got, ref = sims512
+    lab_gpu = vt.assign_labels(got)
+    lab_ref = osim.assign_labels([ref[k] for k in ann])
+    mism = int((lab_gpu != lab_ref).sum())
+    n_lsb = sum(int((got[k] != ref[k]).sum()) for k in ann)
+    print(f'labels: {mism} of {lab_ref.size} voxels differ ({mism / lab_ref.size:.2e}); the 5 maps differ on {n_lsb} voxels')
+    assert len(np.unique(lab_ref)) >= 3
+    assert mism <= n_lsb and mism <= 2e-5 * lab_ref.size
+    assert np.array_equal(lab_gpu, osim.assign_labels([got[k] for k in ann]))      # bit-exact on identical maps
+
+
+def test_config4_bilateral_solver_at_size(gpu, sims512, ct512):
+    """The --bilateral-solver branch at configs[4]'s size: 512^3 volume -> 256^3 maps, two of the five classes against the
+    CPU restatement of the solver (fp64 CG on both sides; the fp32 trilinear resizes may move a voxel across a uint8 /
+    luma-bin edge)."""
+    vol, _ = ct512
+    ann, feat, _, _ = sims512
+    sub = {k: ann[k] for k in ('ntf2', 'ntf3')}
+    got = vt.compute_similarities(vol, feat, sub, bilateral_solver=True)
+    ref = osim.similarity_maps(tuple(vol.shape), feat.float().cpu(), sub, volume=vol.float())
+    for k in sub:
+        assert got[k].shape == (256, 256, 256) and got[k].dtype == torch.uint8
+        d = (got[k].int() - ref[k].int()).abs()
+        d = torch.minimum(d, 256 - d)
+        frac = float((d > 0).float().mean())
+        print(f'bilateral {k}: {frac:.2e} of the voxels differ, max |diff| {int(d.max())}, '
+              f'{float((d > 1).float().mean()):.2e} by more than 1 step')
+        assert int(ref[k].max()) >= 250 and frac <= 0.01 and float((d > 1).float().mean()) <= 1e-3, k

@@ -164,22 +164,41 @@ def _attn_ref(qkv, batch, tokens, heads, pre=0):
     return (att.softmax(-1) @ v).transpose(1, 2).reshape(batch * tokens, d)
 
 
-def _run_attn(gpu, qkv, batch, tokens, heads, dt, pre=0):
+ATTN_VARIANTS = ['plain', 'pipe', 'lazy']   # q as produced | pre-scaled q, software-pipelined kernel (default) | pre-scaled q, round-1 kernel
+
+
+def _attn_variant(variant):
+    """-> q_prescaled flag; selects the kernel behind vittf_attention(q_prescaled = 1) through its (per-call) switch."""
+    import os
+    if variant == 'lazy':
+        os.environ['VITTF_ATTN_PIPE'] = '0'
+    else:
+        os.environ.pop('VITTF_ATTN_PIPE', None)
+    return 0 if variant == 'plain' else 1
+
+
+def _run_attn(gpu, qkv, batch, tokens, heads, dt, pre=0, pad_rows=2):
+    import os
     lib = _lib.load()
     qd = qkv.to(gpu)
-    out = torch.full((batch * tokens + 2, heads * 64), 7.0, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], pre, _lib.stream_ptr()))
-    torch.cuda.synchronize()
+    out = torch.full((batch * tokens + pad_rows, heads * 64), 7.0, dtype=TDT[dt], device=gpu)
+    try:
+        _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], pre, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop('VITTF_ATTN_PIPE', None)
     got = out.float().cpu().double()
     assert (got[batch * tokens:] == 7.0).all(), 'wrote past the last row'
     return got[:batch * tokens]
 
 
-@pytest.mark.parametrize('pre', [0, 1])
+@pytest.mark.parametrize('variant', ATTN_VARIANTS)
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-@pytest.mark.parametrize('batch,tokens,heads', [(1, 1, 2), (2, 17, 2), (1, 64, 2), (3, 65, 2), (1, 128, 6), (2, 129, 2),
-                                                (1, 200, 6), (2, 577, 2), (1, 1025, 2)])
-def test_attention_small(gpu, dt, batch, tokens, heads, pre):
+@pytest.mark.parametrize('batch,tokens,heads', [(1, 1, 2), (2, 17, 2), (1, 33, 2), (1, 64, 2), (3, 65, 2), (1, 128, 6), (2, 129, 2),
+                                                (1, 192, 2), (1, 200, 6), (2, 257, 2), (1, 320, 2), (2, 577, 2), (1, 1025, 2)])
+def test_attention_small(gpu, dt, batch, tokens, heads, variant):
+    """Token counts cover 1..17 key tiles of 64: every remainder path of the pipelined kernel's 3-deep ring."""
+    pre = _attn_variant(variant)
     g = gen(batch * 1000 + tokens)
     qkv = torch.randn(batch * tokens, 3 * heads * 64, generator=g)
     qkv[:, :2 * heads * 64] *= 1.6          # logits with a std of ~2.5: a peaked softmax
@@ -192,19 +211,20 @@ def test_attention_small(gpu, dt, batch, tokens, heads, pre):
     assert max_abs(got, ref) <= 6 * EPS[dt] * vmax
 
 
-@pytest.mark.parametrize('pre', [0, 1])
+@pytest.mark.parametrize('variant', ATTN_VARIANTS)
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('gain', [12.0, 60.0])
-def test_attention_rescale_branch(gpu, dt, pre, gain):
+def test_attention_rescale_branch(gpu, dt, variant, gain):
     """Force the maximum to jump in a late key tile and in the ragged last tile: the online-softmax rescale path of
     the plain kernel and the overflow-triggered slow path of the lazy-maximum kernel (gain 60: scores 2^170 above
     the first tile's, past fp32's exponent range); a uniform-random check exercises neither."""
+    pre = _attn_variant(variant)
     batch, tokens, heads = 1, 333, 2
     g = gen(4)
     qkv = torch.randn(batch * tokens, 3 * heads * 64, generator=g) * 0.5
     q = qkv[:, :128].view(tokens, 2, 64)
     k = qkv[:, 128:256].view(tokens, 2, 64)
-    for key_row in (5, 200, 332):                       # first tile, a middle tile, the ragged last tile
+    for key_row in (5, 100, 200, 332):                  # first tile, both halves of middle tiles, the ragged last tile
         k[key_row, 0] = q[7 + key_row % 50, 0] * gain   # one query row suddenly matches this key strongly
     k[40, 1] = q[3, 1] * -gain                          # and one strongly negative score
     qkv = _prescale(qkv, heads, dt) if pre else qkv.to(TDT[dt])
@@ -215,10 +235,11 @@ def test_attention_rescale_branch(gpu, dt, pre, gain):
     assert max_abs(got, ref) <= 6 * EPS[dt] * float(qkv[:, 256:].float().abs().max())
 
 
-@pytest.mark.parametrize('pre', [0, 1])
+@pytest.mark.parametrize('variant', ATTN_VARIANTS)
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-def test_attention_full_size(gpu, dt, pre):
+def test_attention_full_size(gpu, dt, variant):
     """N = 4097 (512^2 image, P = 8), 6 heads: the headline shape; reference in fp64 on the GPU via torch ops."""
+    pre = _attn_variant(variant)
     batch, tokens, heads = 2, 4097, 6
     g = gen(77)
     qkv = torch.randn(batch * tokens, 3 * heads * 64, generator=g)
@@ -227,7 +248,11 @@ def test_attention_full_size(gpu, dt, pre):
     lib = _lib.load()
     qd = qkv.to(gpu)
     out = torch.zeros(batch * tokens, heads * 64, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], pre, _lib.stream_ptr()))
+    try:
+        _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], pre, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        _attn_variant('plain')
     x = qd.double().view(batch, tokens, 3, heads, 64)
     err2, ref2, mx = 0.0, 0.0, 0.0
     for b in range(batch):
@@ -238,6 +263,34 @@ def test_attention_full_size(gpu, dt, pre):
             err2 += float((d * d).sum()); ref2 += float((r * r).sum()); mx = max(mx, float(d.abs().max()))
     assert (err2 / ref2) ** 0.5 <= 3 * EPS[dt]
     assert mx <= 6 * EPS[dt] * float(qkv[:, 2 * heads * 64:].float().abs().max())
+
+
+@pytest.mark.parametrize('variant', ATTN_VARIANTS)
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('tokens', [65, 4097])
+def test_attention_ignores_what_lies_behind_the_slices(gpu, dt, variant, tokens):
+    """The ragged last key tile reaches past the last token of a slice.  Whatever lies there -- the next slice's rows, or
+    for the last slice of a batch the engine's un-stored workspace padding, which is torch.empty memory -- must not reach
+    the output: P = 0 times a NaN / Inf bit pattern would poison every row of the (slice, head).  The qkv buffer gets 80
+    rows of 0x7FFF (NaN in both 16-bit types) behind the batch; results must be finite and equal to those of a buffer
+    padded with zeros, bit for bit."""
+    pre = _attn_variant(variant)
+    batch, heads = 2, 2
+    g = gen(tokens)
+    qkv = torch.randn(batch * tokens, 3 * heads * 64, generator=g)
+    qkv[:, :2 * heads * 64] *= 1.5
+    qkv = _prescale(qkv, heads, dt) if pre else qkv.to(TDT[dt])
+    pad = 80
+    poisoned = torch.cat([qkv, torch.full((pad, qkv.shape[1]), float('nan')).to(TDT[dt])])
+    assert int(poisoned[-1].view(torch.int16)[0]) & 0x7FFF >= 0x7F80       # really a NaN pattern in the 16-bit type
+    clean = torch.cat([qkv, torch.zeros(pad, qkv.shape[1]).to(TDT[dt])])
+    got_p = _run_attn(gpu, poisoned, batch, tokens, heads, dt, pre)
+    _attn_variant(variant)
+    got_c = _run_attn(gpu, clean, batch, tokens, heads, dt, pre)
+    assert torch.isfinite(got_p).all()
+    assert torch.equal(got_p, got_c)
+    if tokens <= 128:
+        assert rel_fro(got_p, _attn_ref(qkv, batch, tokens, heads, pre)) <= 3 * EPS[dt]
 
 
 # ------------------------------------------------------------------------------------------ front end
@@ -758,3 +811,74 @@ def test_confusion_matrix_matches_numpy(gpu, n, classes):
         want = osim.evaluate_predictions(pb.numpy(), tb.numpy())
         assert acc == want['accuracy'] and prec.tolist() == want['precision'] and rec.tolist() == want['recall']
         assert f1.tolist() == want['f1'] and iou.tolist() == want['iou'] and cm.tolist() == want['confusion_matrix']
+
+
+# ---------------------------------------------------------------- volume I/O + resize formats
+@pytest.mark.parametrize('shape,out', [((8, 9, 10), (16, 18, 20)), ((7, 5, 3), (13, 11, 17)), ((16, 16, 16), (8, 8, 8)),
+                                       ((5, 6, 40), (10, 12, 33)), ((12, 10, 64), (24, 20, 128)), ((3, 3, 3), (3, 3, 3))])
+def test_resize_nearest_u8_matches_interpolate(gpu, shape, out):
+    """predict_ntf.py:217-218 (label up-sample) and evaluate_similarities.py:63 (class-mask resize): bit-exact against
+    F.interpolate(mode='nearest') on the CPU, aligned (16-byte stores) and ragged fast dims, up- and down-sampling."""
+    lab = torch.randint(0, 6, shape, generator=gen(sum(shape)), dtype=torch.uint8)
+    ref = F.interpolate(lab[None, None], out, mode='nearest')[0, 0]
+    got = vt.scores.resize_nearest_u8(lab.numpy(), out)
+    assert got.dtype == np.uint8 and got.shape == out and np.array_equal(got, ref.numpy())
+    for cls in (0, 3):
+        mask_ref = F.interpolate((lab == cls).to(torch.uint8)[None, None], out, mode='nearest')[0, 0]
+        got = vt.scores.resize_nearest_u8(lab, out, equals=cls, keep_on_device=True)
+        assert got.is_cuda and torch.equal(got.cpu(), mask_ref)
+    lib = _lib.load()
+    d = lab.to(gpu)
+    assert lib.vittf_resize_nearest_u8(_lib.ptr(d), 8, 9, 10, _lib.ptr(d), 8, 9, 10, -1, _lib.stream_ptr()) == -1   # in place
+
+
+def test_fp16_volume_is_widened_on_the_device(gpu):
+    """A volume stored as fp16 (create_synthetic_volumes.py:44-46) is uploaded as 2-byte values and widened in HBM: same
+    fp32 values, min / max and features as the host-side .float() of infer.py:137."""
+    for shape in ((24, 16, 32), (5, 7, 9)):
+        vol = (torch.randn(shape, generator=gen(3)) * 300).half()
+        a = vt.DeviceVolume(vol, gpu)
+        b = vt.DeviceVolume(vol.float(), gpu)
+        assert a.data.dtype == torch.float32 and torch.equal(a.data, b.data) and torch.equal(a.minmax, b.minmax)
+        assert torch.equal(a.data.cpu(), vol.float())
+
+
+def test_empty_class_keeps_its_key(gpu):
+    """An annotation class without points keeps its key with an all-zero map (the reference: mean over an empty slice ->
+    NaN -> uint8 0, predict_ntf.py:46-49, 70-72, 99), so the label ids of the later classes do not shift."""
+    g = gen(5)
+    feat = F.normalize(torch.randn(64, 6, 7, 8, generator=g), dim=0).half()
+    shape = (12, 14, 16)
+    full = {'a': torch.tensor([[2, 3, 4], [7, 7, 7]]), 'b': torch.tensor([[5, 9, 2], [1, 1, 1], [11, 13, 15]])}
+    holed = {'a': full['a'], 'gap': torch.zeros((0, 3), dtype=torch.int64), 'b': full['b']}
+    vol = np.zeros(shape, np.float32)
+    ref = vt.compute_similarities(vol, feat, full)
+    got = vt.compute_similarities(vol, feat, holed)
+    assert list(got) == ['a', 'gap', 'b']
+    assert torch.equal(got['a'], ref['a']) and torch.equal(got['b'], ref['b'])
+    assert got['gap'].dtype == torch.uint8 and got['gap'].shape == ref['a'].shape and int(got['gap'].max()) == 0
+    dev = vt.compute_similarities(vol, feat, holed, keep_on_device=True)
+    assert all(v.is_cuda for v in dev.values())
+    lab = vt.assign_labels(got)
+    want = osim.assign_labels([ref['a'], torch.zeros_like(ref['a']), ref['b']])
+    assert np.array_equal(lab, want) and set(np.unique(lab)) <= {0, 1, 3}
+    assert vt.compute_similarities(vol, feat, {'gap': torch.zeros((0, 3), dtype=torch.int64)}) is None
+
+
+@pytest.mark.parametrize('f,n', [(64, (6, 7, 8)), (384, (16, 16, 16))])
+def test_similarity_single_annotation(gpu, f, n):
+    """One query voxel in total (BASELINE configs[0]: '1 similarity query').  The intended map -- the reference's
+    .squeeze(1) (predict_ntf.py:65) drops the annotation axis in exactly this case, so the oracle
+    computes the mathematically intended map, as the GPU path does."""
+    g = gen(f)
+    feat = F.normalize(torch.randn(f, *n, generator=g), dim=0)
+    feat = F.normalize(feat + 0.6 * feat[:, 2:3, 3:4, 4:5], dim=0).half()
+    shape = tuple(2 * s for s in n)
+    ann = {'ntf1': torch.tensor([[4, 6, 8]])}
+    got = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann)
+    ref = osim.similarity_maps(shape, feat.float(), ann)
+    assert list(got) == ['ntf1'] and got['ntf1'].shape == ref['ntf1'].shape and int(ref['ntf1'].max()) > 200
+    d = (got['ntf1'].int() - ref['ntf1'].int()).abs()
+    d = torch.minimum(d, 256 - d)
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01
+    assert np.array_equal(vt.assign_labels(got), osim.assign_labels([got['ntf1']]))

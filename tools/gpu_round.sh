@@ -25,6 +25,14 @@ for s in "$@"; do
     prof)     cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               export VITTF_BENCH_OVERLAP=0   # the profile is of the contract measurement (one lane), not of the two-lane leg
               step rocprof 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 1 --warmup 1 --workload 64 --cpu-slices 0 ;;
+    attn)     step test_attn 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider -k "attention or resize or widened or empty_class or single_annotation" ;;
+    fullsize) step test_fullsize 1100 python -m pytest tests/test_gpu_fullsize.py -q -m gpu -s -p no:cacheprovider ;;
+    attnbench) for dt in fp16 bf16; do for pipe in 1 0; do
+                 DT=$dt VITTF_ATTN_PIPE=$pipe step attnbench_${dt}_pipe$pipe 300 python tools/bench_kernels.py attn; done; done ;;
+    bench512) step bench512 900 python bench.py ;;
+    prof512)  cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
+              export VITTF_BENCH_OVERLAP=0
+              step rocprof512 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof512 -- python bench.py --steps 1 --warmup 1 --cpu-slices 0 ;;
     *) echo "unknown step $s" ;;
   esac
 done

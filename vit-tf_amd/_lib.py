@@ -84,6 +84,8 @@ SIGNATURES = {
     'vittf_surface_shell_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'vittf_surface_shell': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     'vittf_confusion_matrix': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    'vittf_resize_nearest_u8': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'vittf_widen_f16': (C.c_int, [_vp, _i64, _vp, _vp]),
     'vittf_bilateral_workspace_bytes': (_sz, [_i32, _i32, _i32, C.c_double, _i32]),
     'vittf_bilateral_refine': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _P(_i32), _i32,
                                          _P(BilateralParams), _vp, _P(_i32), _vp, _sz, _vp]),
@@ -108,13 +110,15 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.vittf_abi_version() != 1:
+    if lib.vittf_abi_version() != ABI_VERSION:
         raise VittfError('libvittf.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib
 
 
-KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention', 'mlp')
+KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention', 'mlp', 'gemm_qkv', 'gemm_proj', 'gemm_fc1', 'gemm_fc2',
+                  'similarity')
+ABI_VERSION = 2
 
 
 def profiler_enable(on=True, classes=None):

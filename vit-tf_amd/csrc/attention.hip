@@ -24,6 +24,8 @@
 //   * workgroups are remapped so that the q-tiles of one (slice, head) share an XCD's L2 (K/V re-reads)
 #include "attn_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int QT = 128;   // query rows per workgroup
@@ -219,16 +221,28 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned s
     voff_v1 = v_src(256 + tid);
   }
   const int tile_stride = KT * ld * 2;
+  const int nt = (tokens + KT - 1) / KT;
   // wave-uniform LDS byte address; the hardware adds lane * 16.  (asm pieces, see lds_dma16: with the builtin hipcc
   // put s_waitcnt vmcnt(0) in front of the V reads in the middle of every tile.)
   const unsigned dma_dst = (unsigned)(size_t)LDS_PTR(smem) + (__builtin_amdgcn_readfirstlane(tid & ~63) << 4);
+  // The LAST tile (the only one that can reach past the slice's rows) carries its tile offset in the per-lane voffset:
+  // that is the operand the descriptor's range check is documented to cover, so rows >= tokens arrive as zeros whatever
+  // lies behind the slice (the next slice's rows, or uninitialised workspace whose NaN / Inf bit patterns would turn
+  // P = 0 times V into NaN).  Every other tile keeps the offset in the scalar operand: no VALU on the hot path.
 #define ATTN_STAGE_TILE(t, BUFI)                                                                              \
   {                                                                                                           \
     const int so_ = (t) * tile_stride;                                                                        \
-    lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES, voff_k0, so_);                                                 \
-    lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + 4096, voff_k1, so_);                                          \
-    lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES, voff_v0, so_);                                 \
-    lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES + 4096, voff_v1, so_);                          \
+    if ((t) == nt - 1) {                                                                                      \
+      lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES, voff_k0 + so_, 0);                                           \
+      lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + 4096, voff_k1 + so_, 0);                                    \
+      lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES, voff_v0 + so_, 0);                           \
+      lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES + 4096, voff_v1 + so_, 0);                    \
+    } else {                                                                                                  \
+      lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES, voff_k0, so_);                                               \
+      lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + 4096, voff_k1, so_);                                        \
+      lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES, voff_v0, so_);                               \
+      lds_dma16(rsrc, dma_dst + (BUFI) * BUF_BYTES + KV_TILE_BYTES + 4096, voff_v1, so_);                        \
+    }                                                                                                         \
   }
 
   // ---- per-lane LDS read bases (see tile_off / v_off: the kt, s2, dvt, jj and buffer terms are immediates) ----
@@ -251,7 +265,6 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned s
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; negm[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
-  const int nt = (tokens + KT - 1) / KT;
   ATTN_STAGE_TILE(0, 0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -316,6 +329,9 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned s
 
 }  // namespace
 
+int vittf_attention_pipe(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
+                         hipStream_t st);                                                        // attention_pipe.hip
+
 extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads,
                                int32_t dtype, int32_t q_prescaled, void* stream) {
   if (!qkv || !out || batch <= 0 || tokens <= 0 || heads <= 0) return VITTF_ERR_INVALID_ARG;
@@ -327,6 +343,12 @@ extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_
   const int total = (int)total64;
   const float c = 0.125f * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)stream;
+  if (q_prescaled && (dtype == VITTF_BF16 || dtype == VITTF_FP16)) {
+    // default for pre-scaled q: the software-pipelined kernel (attention_pipe.hip); VITTF_ATTN_PIPE=0 keeps the
+    // round-1 lazy-maximum kernel below (read per call: the tests switch it)
+    const char* e = getenv("VITTF_ATTN_PIPE");
+    if (!e || atoi(e) != 0) return vittf_attention_pipe(qkv, out, batch, tokens, heads, dtype, st);
+  }
 #define VITTF_ATTN_LAUNCH(DTV, PREV)                                                                        \
   hipLaunchKernelGGL((attn_kernel<DTV, PREV>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,   \
                      (unsigned short*)out, tokens, heads, q_tiles, total, c)

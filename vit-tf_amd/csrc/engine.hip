@@ -31,14 +31,6 @@ hipEvent_t prof_event() {
   return e;
 }
 
-struct ProfScope {
-  ProfRec r; hipStream_t st; bool on;
-  ProfScope(int cls, void* stream) : st((hipStream_t)stream), on((g_prof_mask >> cls) & 1u) {
-    if (on) { r.cls = cls; r.a = prof_event(); r.b = prof_event(); (void)hipEventRecord(r.a, st); }
-  }
-  ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof_recs.push_back(r); } }
-};
-
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
@@ -63,6 +55,20 @@ bool config_ok(const vittf_vit_config* c) {
          (c->dtype == VITTF_BF16 || c->dtype == VITTF_FP16) && c->ln_eps > 0.f;
 }
 }  // namespace
+
+void* vittf_prof_begin(int cls, void* stream) {
+  if (!((g_prof_mask >> cls) & 1u)) return nullptr;
+  ProfRec* r = new ProfRec;
+  r->cls = cls; r->a = prof_event(); r->b = prof_event();
+  (void)hipEventRecord(r->a, (hipStream_t)stream);
+  return r;
+}
+void vittf_prof_end(void* token, void* stream) {
+  ProfRec* r = (ProfRec*)token;
+  (void)hipEventRecord(r->b, (hipStream_t)stream);
+  g_prof_recs.push_back(*r);
+  delete r;
+}
 
 extern "C" int vittf_abi_version(void) { return VITTF_ABI_VERSION; }
 
@@ -137,7 +143,7 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
     }
     if (l == L - 1) {
       // hooked tensor, one third only: rows [part*D, (part+1)*D) of qkv.weight / qkv.bias  (infer.py:189-201)
-      ProfScope ps(VITTF_KERNEL_GEMM, stream);
+      ProfScope ps(VITTF_KERNEL_GEMM, stream);   // the K-feature projection (tiled kernel)
       return vittf_gemm(H, qkv_w + (size_t)qkv_part * d * d * esz, w->qkv_b + (size_t)l * 3 * d + (size_t)qkv_part * d,
                         k_out, rows, d, d,
                         VITTF_EPI_KFEAT, tokens, dt, stream);
@@ -145,7 +151,7 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
     // Default: q pre-scaled by log2(e)/8 in the qkv epilogue + the lazy-maximum attention kernel (168 VGPRs, 3 waves per
     // SIMD): 0.78 ms per launch in the pipeline against 0.87 ms for the online-maximum kernel (VITTF_ATTN_PRESCALED=0).
     static const int pre = [] { const char* e = getenv("VITTF_ATTN_PRESCALED"); return e ? atoi(e) : 1; }();
-    { ProfScope ps(VITTF_KERNEL_GEMM, stream);
+    { ProfScope ps(VITTF_KERNEL_GEMM_QKV, stream);
       if (ln_fused)
         rc = vittf_ln_gemm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, cfg->ln_eps, qkv_w,
                            w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, dt,
@@ -157,7 +163,7 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
     { ProfScope ps(VITTF_KERNEL_ATTENTION, stream);
       rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, pre, stream); }
     if (rc) return rc;
-    { ProfScope ps(VITTF_KERNEL_GEMM, stream);
+    { ProfScope ps(VITTF_KERNEL_GEMM_PROJ, stream);
       if (res_ln)
         rc = vittf_gemm_residual_ln(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d,
                                     d, dt, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, cfg->ln_eps, H, stream);
@@ -177,7 +183,7 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
                            dt, stream);
       if (rc) return rc;
     } else {
-      { ProfScope ps(VITTF_KERNEL_GEMM, stream);
+      { ProfScope ps(VITTF_KERNEL_GEMM_FC1, stream);
         if (ln_fused)
           rc = vittf_ln_gemm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, cfg->ln_eps,
                              (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows, 4 * d,
@@ -186,7 +192,7 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
           rc = vittf_gemm(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows,
                           4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream); }
       if (rc) return rc;
-      { ProfScope ps(VITTF_KERNEL_GEMM, stream);
+      { ProfScope ps(VITTF_KERNEL_GEMM_FC2, stream);
         if (res_ln)   // (l + 1 < L always holds here: the last block returns above)
           rc = vittf_gemm_residual_ln(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows,
                                       d, 4 * d, dt, w->ln1_g + (size_t)(l + 1) * d, w->ln1_b + (size_t)(l + 1) * d,

@@ -436,6 +436,7 @@ int accumulate_class_maps(const void* feat, bool half, int32_t f, int64_t nvox, 
   if (mode == 0 && half && mfma_ws_bytes) {   // many annotations, F = 384: the volume is read once (sim_mfma.hip)
     static const bool use_mfma = [] { const char* e = getenv("VITTF_SIM_MFMA"); return !e || atoi(e) != 0; }();
     if (use_mfma) {
+      ProfScope ps(VITTF_KERNEL_SIMILARITY, st);
       const int rc = vittf_sim_mfma_maps((const unsigned short*)feat, f, nvox, qf, class_start_host, classes, voxel_norm, sim,
                                          maxbits, mfma_ws, mfma_ws_bytes, st);
       if (rc != 1) return rc;
@@ -480,10 +481,13 @@ int accumulate_class_maps(const void* feat, bool half, int32_t f, int64_t nvox, 
     else hipLaunchKernelGGL((sim_accumulate<BIG, ACT, HALF>), dim3(blocks), dim3(256), 0, st, feat, f, nvox, qf_t, ch,   \
                             voxel_norm, expo, sim, maxbits);                                                             \
   }
-    if (mode == 1) SIM_LAUNCH(true, 0, true)
-    else if (mode == 0) SIM_LAUNCH(false, 0, true)
-    else if (half) SIM_LAUNCH(false, 1, true)
-    else SIM_LAUNCH(false, 1, false)
+    {
+      ProfScope ps(VITTF_KERNEL_SIMILARITY, st);
+      if (mode == 1) SIM_LAUNCH(true, 0, true)
+      else if (mode == 0) SIM_LAUNCH(false, 0, true)
+      else if (half) SIM_LAUNCH(false, 1, true)
+      else SIM_LAUNCH(false, 1, false)
+    }
 #undef SIM_LAUNCH
     a0 += n;
   }

@@ -128,6 +128,16 @@ __device__ __forceinline__ void lds_dma16_flat(const void* gsrc, unsigned lds_ad
                : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
 }
 
+// ---- optional per-kernel-class timing with HIP events on the launch stream (engine.hip; bench.py's roofline legs) ----
+// Not part of the C ABI (C++ linkage).  begin returns a token (or null when the class is not being recorded).
+void* vittf_prof_begin(int cls, void* stream);
+void vittf_prof_end(void* token, void* stream);
+struct ProfScope {
+  void* tok; void* st;
+  ProfScope(int cls, void* stream) : tok(vittf_prof_begin(cls, stream)), st(stream) {}
+  ~ProfScope() { if (tok) vittf_prof_end(tok, st); }
+};
+
 static inline int vittf_check_launch() {
   return hipGetLastError() == hipSuccess ? VITTF_OK : VITTF_ERR_LAUNCH;
 }

@@ -111,6 +111,67 @@ __global__ __launch_bounds__(256) void assemble_sum_kernel(const unsigned short*
   }
 }
 
+
+// ---- nearest resize of a uint8 volume (labels / class masks) and fp16 -> fp32 widening of an uploaded volume ----
+// F.interpolate(..., mode='nearest') on a 5-D tensor: src = min(floor(dst * (float)in / out), in - 1) per dim
+// (predict_ntf.py:217-218 label up-sample to the volume size, evaluate_similarities.py:63 class-mask resize).
+// One thread = 16 consecutive outputs of the fast dim (one 16-byte store); the byte gathers hit L1 / L2.
+__global__ __launch_bounds__(256) void resize_nearest_u8_kernel(const unsigned char* __restrict__ src, int n0, int n1, int n2,
+                                                                unsigned char* __restrict__ dst, int o0, int o1, int o2,
+                                                                int equals) {
+  const float s0 = (float)n0 / (float)o0, s1 = (float)n1 / (float)o1, s2 = (float)n2 / (float)o2;
+  const int cz = (o2 + 15) / 16;                       // 16-byte chunks per output row
+  const int64_t chunks = (int64_t)o0 * o1 * cz;
+  const bool aligned = (o2 % 16 == 0) && (((uintptr_t)dst & 15) == 0);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < chunks; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % cz);
+    int64_t t = e / cz;
+    const int y = (int)(t % o1);
+    const int x = (int)(t / o1);
+    int sx = (int)floorf((float)x * s0), sy = (int)floorf((float)y * s1);
+    sx = sx < n0 - 1 ? sx : n0 - 1; sy = sy < n1 - 1 ? sy : n1 - 1;
+    const unsigned char* row = src + ((int64_t)sx * n1 + sy) * n2;
+    unsigned char* orow = dst + ((int64_t)x * o1 + y) * o2 + 16 * c;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    const int nz = min(16, o2 - 16 * c);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < nz) {
+        int sz = (int)floorf((float)(16 * c + j) * s2);
+        sz = sz < n2 - 1 ? sz : n2 - 1;
+        unsigned v = row[sz];
+        if (equals >= 0) v = (v == (unsigned)equals) ? 1u : 0u;
+        w[j >> 2] |= v << (8 * (j & 3));
+      }
+    }
+    if (aligned) {
+      *reinterpret_cast<uint4*>(orow) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      for (int j = 0; j < nz; ++j) orow[j] = (unsigned char)(w[j >> 2] >> (8 * (j & 3)));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void widen_f16_kernel(const unsigned short* __restrict__ src, int64_t n,
+                                                        float* __restrict__ dst) {
+  const int64_t n8 = n >> 3;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+    const uint4 u = reinterpret_cast<const uint4*>(src)[e];
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    float4 a, b;
+    a.x = f16bits_to_f32((unsigned short)(w[0] & 0xffff)); a.y = f16bits_to_f32((unsigned short)(w[0] >> 16));
+    a.z = f16bits_to_f32((unsigned short)(w[1] & 0xffff)); a.w = f16bits_to_f32((unsigned short)(w[1] >> 16));
+    b.x = f16bits_to_f32((unsigned short)(w[2] & 0xffff)); b.y = f16bits_to_f32((unsigned short)(w[2] >> 16));
+    b.z = f16bits_to_f32((unsigned short)(w[3] & 0xffff)); b.w = f16bits_to_f32((unsigned short)(w[3] >> 16));
+    reinterpret_cast<float4*>(dst)[2 * e] = a;
+    reinterpret_cast<float4*>(dst)[2 * e + 1] = b;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const int64_t i = (n8 << 3) + threadIdx.x;
+    dst[i] = f16bits_to_f32(src[i]);
+  }
+}
+
 }  // namespace
 
 extern "C" int vittf_pool_slices(const uint16_t* k_slices, int32_t k_slice0, int32_t k_nslices, int32_t total_slices,
@@ -152,5 +213,26 @@ extern "C" int vittf_assemble_sum(const uint16_t* gz, const uint16_t* gy, const 
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(assemble_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gz, gy, gx,
                      chunk[2], chunk[1], chunk[0], d, n0, n1, n2, out);
+  return vittf_check_launch();
+}
+
+extern "C" int vittf_resize_nearest_u8(const uint8_t* src, int32_t n0, int32_t n1, int32_t n2, uint8_t* dst, int32_t o0,
+                                       int32_t o1, int32_t o2, int32_t equals, void* stream) {
+  if (!src || !dst || src == dst || n0 <= 0 || n1 <= 0 || n2 <= 0 || o0 <= 0 || o1 <= 0 || o2 <= 0 || equals > 255)
+    return VITTF_ERR_INVALID_ARG;
+  const int64_t chunks = (int64_t)o0 * o1 * ((o2 + 15) / 16);
+  int64_t blocks = (chunks + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(resize_nearest_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, n0, n1, n2,
+                     dst, o0, o1, o2, equals);
+  return vittf_check_launch();
+}
+
+extern "C" int vittf_widen_f16(const uint16_t* src, int64_t n, float* dst, void* stream) {
+  if (!src || !dst || n <= 0 || ((uintptr_t)src & 15) != 0 || ((uintptr_t)dst & 15) != 0) return VITTF_ERR_INVALID_ARG;
+  int64_t blocks = ((n >> 3) + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(widen_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, n, dst);
   return vittf_check_launch();
 }

@@ -29,11 +29,12 @@ class HipViT:
     """Weights + workspace of one ViT on one GPU.
 
     state_dict: DINO-layout tensors (fp32, CPU or GPU).  arch: DINO name ('vits8', ...) or
-    (embed_dim, depth, heads, patch).  dtype: 'bf16' (default, BASELINE config) or 'fp16'
-    (the reference's own GPU autocast type, infer.py:309) for the MFMA operands.
+    (embed_dim, depth, heads, patch).  dtype of the MFMA operands: 'fp16' (default: the reference's own GPU autocast
+    type, infer.py:309; meets the 1e-3 parity bound against the fp32 CPU path) or 'bf16' (opt-in: 8-bit mantissa,
+    2.4e-3 .. 3.9e-3 against the CPU path).
     """
 
-    def __init__(self, state_dict, arch='vits8', dtype='bf16', device=None, fused_mlp=None):
+    def __init__(self, state_dict, arch='vits8', dtype='fp16', device=None, fused_mlp=None):
         self.lib = _lib.require_device()
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         dim, depth, heads, patch = arch_of(arch)

@@ -56,7 +56,16 @@ class DeviceVolume:
         if vol.ndim != 3:
             raise ValueError(f'volume must be 3-D, got shape {tuple(vol.shape)}')
         self.shape = tuple(vol.shape)
-        self.data = vol.to(device=device, dtype=torch.float32).contiguous()
+        if vol.dtype == torch.float16 and not vol.is_cuda:
+            # volumes are stored as fp16 (create_synthetic_volumes.py:44-46): upload the 2-byte form and widen it in HBM
+            # (vol.float(), infer.py:137) -- half the PCIe bytes of a host-side conversion
+            raw = vol.contiguous().to(device=device)
+            self.data = torch.empty(self.shape, dtype=torch.float32, device=device)
+            _lib.check(lib.vittf_widen_f16(_lib.ptr(raw), raw.numel(), _lib.ptr(self.data), _lib.stream_ptr()),
+                       'vittf_widen_f16')
+            del raw
+        else:
+            self.data = vol.to(device=device, dtype=torch.float32).contiguous()
         self.minmax = torch.empty(2, dtype=torch.float32, device=device)
         ws = torch.empty(lib.vittf_minmax_workspace_bytes(), dtype=torch.uint8, device=device)
         _lib.check(lib.vittf_volume_minmax(_lib.ptr(self.data), self.data.numel(), _lib.ptr(self.minmax), _lib.ptr(ws),

@@ -47,3 +47,22 @@ def scores_from_confusion(cm):
 
 def scores(target, pred, classes=None):
     return scores_from_confusion(confusion_matrix(target, pred, classes))
+
+
+def resize_nearest_u8(vol, out_shape, equals=None, keep_on_device=False):
+    """F.interpolate(make_5d(vol), out_shape, mode='nearest') of a uint8 volume on the GPU (vittf_resize_nearest_u8):
+    the label up-sample of predict_ntf.py:217-218, or -- with `equals` -- the resized class mask
+    F.interpolate((labels == equals).to(uint8)[None, None], out_shape, mode='nearest') of evaluate_similarities.py:63.
+    vol: numpy / CPU / GPU uint8-valued (n0, n1, n2).  Returns a uint8 numpy array (or device tensor)."""
+    lib = _lib.require_device()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    t = torch.as_tensor(np.ascontiguousarray(vol) if isinstance(vol, np.ndarray) else vol).squeeze()
+    if t.ndim != 3:
+        raise ValueError(f'expected a 3-D volume, got {tuple(t.shape)}')
+    t = t.to(dev, torch.uint8).contiguous()
+    out_shape = tuple(int(x) for x in out_shape)
+    out = torch.empty(out_shape, dtype=torch.uint8, device=dev)
+    _lib.check(lib.vittf_resize_nearest_u8(_lib.ptr(t), t.shape[0], t.shape[1], t.shape[2], _lib.ptr(out), out_shape[0],
+                                           out_shape[1], out_shape[2], -1 if equals is None else int(equals),
+                                           _lib.stream_ptr()), 'vittf_resize_nearest_u8')
+    return out if keep_on_device else out.cpu().numpy()

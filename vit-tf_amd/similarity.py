@@ -64,8 +64,10 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
     features: (F, W', H', D'); annotations: {name: (n, 3) voxel coords}.
     bilateral_solver=True: every class map is refined by the 3-D bilateral solver against the volume
     (predict_ntf.py:73-96, bilateral.py) before quantisation, instead of the nearest resize.
-    Returns {name: uint8 CPU tensor (W//2, H//2, D//2)}; None when there is nothing to query
-    (predict_ntf.py:51-55).  Classes with zero annotations are skipped.
+    Returns {name: uint8 CPU tensor (W//2, H//2, D//2)} with one entry per key of `annotations`, in its order; None
+    when there is nothing to query (predict_ntf.py:51-55).  A class with zero annotations keeps its key with an all-zero
+    map, as in the reference (the mean over an empty slice is NaN, which its uint8 conversion turns into 0,
+    predict_ntf.py:46-49, 70-72, 99), so the label ids of the later classes do not shift (predict_ntf.py:203-215).
     normalize=True: cosine similarity -- the volume is L2-normalised per voxel first, as
     compare_feat_sampling.py:45 and tests/test_vishum.py:12 do (predict_ntf.py itself does not).
     voxel_norm: voxel_norms(features) computed earlier (an interactive session queries one volume many times);
@@ -120,14 +122,22 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
             refined = bilateral.refine_similarity(maps[i], vol, sim_shape)
             q = bilateral.quantize_u8(refined)
             res[k] = q if keep_on_device else q.cpu()
-        return res
+        return _with_empty_classes(res, annotations, sim_shape, dev, keep_on_device)
     out = torch.empty((nclass, *sim_shape), dtype=torch.uint8, device=dev)
     _lib.check(lib.vittf_similarity(_lib.ptr(feat), f, n0, n1, n2, _lib.ptr(qf),
                                     starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big, _lib.ptr(vnorm),
                                     sim_shape[0], sim_shape[1], sim_shape[2], _lib.ptr(out), _lib.ptr(ws), ws_bytes,
                                     _lib.stream_ptr()), 'vittf_similarity')
     host = out if keep_on_device else out.cpu()
-    return {k: host[i] for i, k in enumerate(names)}
+    return _with_empty_classes({k: host[i] for i, k in enumerate(names)}, annotations, sim_shape, dev, keep_on_device)
+
+
+def _with_empty_classes(res, annotations, sim_shape, dev, keep_on_device):
+    """One entry per annotation key, in annotation order: classes without annotations get an all-zero uint8 map."""
+    if len(res) == len(annotations):
+        return res
+    zero = torch.zeros(sim_shape, dtype=torch.uint8, device=dev if keep_on_device else 'cpu')
+    return {k: res[k] if k in res else zero.clone() for k in annotations}
 
 
 def assign_labels(similarities, thresholds=CT_ORG_THRESHOLDS, device=None):
