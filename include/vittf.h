@@ -203,6 +203,11 @@ int vittf_mlp_fused(const void* h, const void* w1, const float* b1, const void* 
 int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
                     int32_t q_prescaled, void* stream);
 
+/* Diagnostics (tools/ only): after a vittf_attention launch made with VITTF_ATTN_ABLATE=5 in the environment, the shader-
+ * clock and 100 MHz real-time stamps the first waves took around their key loop: out_host[wave][4] = {clock start, clock
+ * end, real-time start, real-time end}.  Synchronises the device; returns the number of waves copied (<= max_waves). */
+int vittf_debug_attention_stamps(uint64_t* out_host, int32_t max_waves);
+
 /* ------------------------------------------------------------------------------------------
  * Feature-volume epilogue (infer.py:201-203 permute_out, :329 AdaptiveAvgPool3d, :330-332 axis sum).
  * ---------------------------------------------------------------------------------------- */

@@ -159,15 +159,23 @@ def test_config4_labels_from_gpu_maps_vs_oracle_maps(sims512):
     assert np.array_equal(lab_gpu, osim.assign_labels([got[k] for k in ann]))      # bit-exact on identical maps
 
 
-def test_config4_bilateral_solver_at_size(gpu, sims512, ct512):
+def test_config4_bilateral_solver_at_size(gpu, sims512):
     """The --bilateral-solver branch at configs[4]'s size: 512^3 volume -> 256^3 maps, two of the five classes against the
     CPU restatement of the solver (fp64 CG on both sides; the fp32 trilinear resizes may move a voxel across a uint8 /
     luma-bin edge)."""
-    vol, _ = ct512
     ann, feat, _, _ = sims512
     sub = {k: ann[k] for k in ('ntf2', 'ntf3')}
+    # The grey reference for the solver is a smooth 512^3 volume with mild noise, NOT the CT-like benchmark volume: on
+    # that one the reference's solver returns an all-zero map (a bilateral vertex whose voxels all have zero Sobel
+    # confidence makes the initial guess b / splat(c) NaN, the NaN spreads through the CG dot products and nan_to_num
+    # (bilateral_solver3d.py:245) turns the whole crop into zeros; the oracle and the GPU path both reproduce that --
+    # checked in round 2 -- but a comparison of two zero maps tests nothing).
+    ax = torch.linspace(-1, 1, 512)
+    vol = 800 * torch.exp(-3 * (ax - 0.1) ** 2).view(-1, 1, 1) * torch.exp(-3 * (ax + 0.2) ** 2).view(1, -1, 1) * \
+        torch.exp(-3 * ax ** 2).view(1, 1, -1) - 300
+    vol = vol + 15 * torch.randn(vol.shape, generator=torch.Generator().manual_seed(5))
     got = vt.compute_similarities(vol, feat, sub, bilateral_solver=True)
-    ref = osim.similarity_maps(tuple(vol.shape), feat.float().cpu(), sub, volume=vol.float())
+    ref = osim.similarity_maps(tuple(vol.shape), feat.float().cpu(), sub, volume=vol)
     for k in sub:
         assert got[k].shape == (256, 256, 256) and got[k].dtype == torch.uint8
         d = (got[k].int() - ref[k].int()).abs()

@@ -282,7 +282,7 @@ def test_attention_ignores_what_lies_behind_the_slices(gpu, dt, variant, tokens)
     qkv = _prescale(qkv, heads, dt) if pre else qkv.to(TDT[dt])
     pad = 80
     poisoned = torch.cat([qkv, torch.full((pad, qkv.shape[1]), float('nan')).to(TDT[dt])])
-    assert int(poisoned[-1].view(torch.int16)[0]) & 0x7FFF >= 0x7F80       # really a NaN pattern in the 16-bit type
+    assert bool(torch.isnan(poisoned[-pad:].float()).all())               # NaN bit patterns in the 16-bit type
     clean = torch.cat([qkv, torch.zeros(pad, qkv.shape[1]).to(TDT[dt])])
     got_p = _run_attn(gpu, poisoned, batch, tokens, heads, dt, pre)
     _attn_variant(variant)
@@ -877,7 +877,7 @@ def test_similarity_single_annotation(gpu, f, n):
     ann = {'ntf1': torch.tensor([[4, 6, 8]])}
     got = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann)
     ref = osim.similarity_maps(shape, feat.float(), ann)
-    assert list(got) == ['ntf1'] and got['ntf1'].shape == ref['ntf1'].shape and int(ref['ntf1'].max()) > 200
+    assert list(got) == ['ntf1'] and got['ntf1'].shape == ref['ntf1'].shape and int(ref['ntf1'].max()) > 50   # (the maximum voxel itself wraps to 1)
     d = (got['ntf1'].int() - ref['ntf1'].int()).abs()
     d = torch.minimum(d, 256 - d)
     assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01

@@ -68,6 +68,7 @@ SIGNATURES = {
     'vittf_ln_gemm': (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'vittf_mlp_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'vittf_debug_attention_stamps': (C.c_int, [_P(C.c_uint64), _i32]),
     'vittf_pool_slices': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64,
                                     _i64, _vp]),
     'vittf_assemble_sum': (C.c_int, [_vp, _vp, _vp, _i32, _P(_i32), _i32, _i32, _i32, _i32, _vp, _vp]),
