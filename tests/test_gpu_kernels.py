@@ -164,7 +164,8 @@ def _attn_ref(qkv, batch, tokens, heads, pre=0):
     return (att.softmax(-1) @ v).transpose(1, 2).reshape(batch * tokens, d)
 
 
-ATTN_VARIANTS = ['plain', 'pipe', 'lazy']   # q as produced | pre-scaled q, software-pipelined kernel (default) | pre-scaled q, round-1 kernel
+# q as produced | pre-scaled q: software-pipelined kernel, 32 rows per wave (default) | its 64-rows-per-wave shape | round-1 kernel
+ATTN_VARIANTS = ['plain', 'pipe', 'pipe64', 'lazy']
 
 
 def _attn_variant(variant):
@@ -172,6 +173,8 @@ def _attn_variant(variant):
     import os
     if variant == 'lazy':
         os.environ['VITTF_ATTN_PIPE'] = '0'
+    elif variant == 'pipe64':
+        os.environ['VITTF_ATTN_PIPE'] = '2'
     else:
         os.environ.pop('VITTF_ATTN_PIPE', None)
     return 0 if variant == 'plain' else 1

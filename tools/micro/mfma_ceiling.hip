@@ -1,0 +1,131 @@
+// Ceiling micro-benchmark for the attention kernel's inner loop on gfx950 (tools only, not part of libvittf).
+//
+// A wave issues v_mfma_f32_32x32x16_f16 from registers (random operands: zeros inflate the clock), optionally with the
+// softmax's VALU mix between consecutive MFMAs (two v_exp_f32, two v_add_f32, one v_cvt_pk per MFMA at head dim 64), and
+// stamps the shader clock (s_memtime) and the 100 MHz counter (s_memrealtime) around the loop.  Reported per variant:
+// cycles per MFMA and wave, the clock the chip holds, and the resulting TFLOP/s of the whole chip -- i.e. what
+// "100 % matrix-pipe busy" and "the VALU-bound limit" mean on this device under this power state.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/micro/mfma_ceiling tools/micro/mfma_ceiling.hip && tools/micro/mfma_ceiling
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// NACC independent accumulators, FILL = 0: bare MFMAs, 1: + the softmax VALU mix per MFMA (on values that do not
+// depend on the MFMA results of this iteration), DEP = 1: a dependent chain on one accumulator
+template <int NACC, int FILL, int MFMA = 1>
+__global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ src, float* __restrict__ out,
+                                                 unsigned long long* __restrict__ stamps, int iters) {
+  const int tid = threadIdx.x, gid = blockIdx.x * 256 + tid;
+  f16x8_t a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = *reinterpret_cast<const f16x8_t*>(src + ((gid * 8 + i) % 4096) * 8);
+    b[i] = *reinterpret_cast<const f16x8_t*>(src + ((gid * 8 + 4 + i) % 4096) * 8);
+  }
+  f32x16_t acc[NACC];
+#pragma unroll
+  for (int n = 0; n < NACC; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  float x[16], s0 = 0.f, s1 = 0.f, eA0 = 0.f, eA1 = 0.f, eB0 = 0.f, eB1 = 0.f;
+  unsigned pk = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = -0.01f * (float)((tid + r) & 63);
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if constexpr (MFMA) acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m & 3], b[m & 3], acc[m % NACC], 0, 0, 0);
+      // exact instruction mixes in asm (nothing for the compiler to hoist, fuse or chain): the adds and the conversion
+      // consume the exps of the PREVIOUS gap (no VALU result is used right after it is produced)
+      float& ea0 = (m & 1) ? eB0 : eA0; float& ea1 = (m & 1) ? eB1 : eA1;       // written in this gap
+      float& eb0 = (m & 1) ? eA0 : eB0; float& eb1 = (m & 1) ? eA1 : eB1;       // written in the previous gap
+      if constexpr (FILL == 1) {        // the head-dim-64 softmax mix: 2 v_exp, 2 v_add, 1 v_cvt_pk per MFMA
+        asm volatile("v_exp_f32 %0, %5\n\tv_exp_f32 %1, %6\n\tv_add_f32 %2, %2, %7\n\tv_add_f32 %3, %3, %8\n\tv_cvt_pk_f16_f32 %4, %7, %8"
+                     : "=&v"(ea0), "=&v"(ea1), "+v"(s0), "+v"(s1), "=&v"(pk) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1));
+      } else if constexpr (FILL == 2) { // two v_exp_f32
+        asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=&v"(ea0), "=&v"(ea1) : "v"(x[0]), "v"(x[1]));
+      } else if constexpr (FILL == 3) { // one v_exp_f32
+        asm volatile("v_exp_f32 %0, %1" : "=&v"(ea0) : "v"(x[0]));
+      } else if constexpr (FILL == 4) { // five plain VALU
+        asm volatile("v_add_f32 %0, %5, %6\n\tv_add_f32 %1, %5, %6\n\tv_add_f32 %2, %2, %7\n\tv_add_f32 %3, %3, %8\n\tv_cvt_pk_f16_f32 %4, %7, %8"
+                     : "=&v"(ea0), "=&v"(ea1), "+v"(s0), "+v"(s1), "=&v"(pk) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1));
+      } else if constexpr (FILL == 5) { // three plain VALU (the mix without its exps)
+        asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_cvt_pk_f16_f32 %2, %3, %4"
+                     : "+v"(s0), "+v"(s1), "=&v"(pk) : "v"(eb0), "v"(eb1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float sum = s0 + s1 + (float)(pk & 1) + eA0 + eA1 + eB0 + eB1;
+#pragma unroll
+  for (int n = 0; n < NACC; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += acc[n][r];
+  out[gid] = sum;
+  if ((tid & 63) == 0) {
+    const int w = gid >> 6;
+    stamps[2 * w] = c1 - c0;
+    stamps[2 * w + 1] = r1 - r0;
+  }
+}
+
+template <int NACC, int FILL, int MFMA = 1> void run(const char* name, int waves_per_simd, const _Float16* src, float* out, unsigned long long* st) {
+  hipDeviceProp_t p;
+  (void)hipGetDeviceProperties(&p, 0);
+  const int cus = p.multiProcessorCount;
+  const int blocks = cus * waves_per_simd;          // 256 threads = 4 waves = one per SIMD
+  const int iters = 20000;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int rep = 0; rep < 3; ++rep) {               // repeat: the clock settles under sustained load
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((mfma_loop<NACC, FILL, MFMA>), dim3(blocks), dim3(256), 0, 0, src, out, st, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+  }
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const int nw = blocks * 4;
+  std::vector<unsigned long long> h(2 * nw);
+  (void)hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> cyc(nw), clk(nw);
+  for (int w = 0; w < nw; ++w) { cyc[w] = (double)h[2 * w]; clk[w] = (double)h[2 * w] / ((double)h[2 * w + 1] / 100e6); }
+  std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+  const double mfmas = 8.0 * iters;
+  const double flops = (double)nw * mfmas * 32 * 32 * 16 * 2;
+  printf("%-44s %d wave(s)/SIMD: %6.1f cycles per MFMA and wave, %5.1f per MFMA and SIMD, clock %.3f GHz, %7.1f TFLOP/s (%.1f %% of 2.5 PF)\n",
+         name, waves_per_simd, cyc[nw / 2] / mfmas, cyc[nw / 2] / mfmas / waves_per_simd, clk[nw / 2] / 1e9, flops / (ms * 1e-3) / 1e12,
+         flops / (ms * 1e-3) / 1e12 / 25.0);
+}
+
+int main() {
+  _Float16* src; float* out; unsigned long long* st;
+  std::vector<_Float16> h(4096 * 8);
+  srand(1);
+  for (auto& v : h) v = (_Float16)((rand() / (float)RAND_MAX - 0.5f) * 2.f);
+  (void)hipMalloc(&src, h.size() * 2);
+  (void)hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  (void)hipMalloc(&out, 256 * 8 * 256 * 4);
+  (void)hipMalloc(&st, 256 * 8 * 4 * 16);
+  for (int w = 1; w <= 3; ++w) {
+    run<4, 0>("bare MFMA, 4 independent accumulators", w, src, out, st);
+    run<1, 0>("bare MFMA, one accumulator chain", w, src, out, st);
+    run<4, 1>("MFMA + 2 v_exp + 2 v_add + 1 v_cvt_pk", w, src, out, st);
+    run<4, 2>("MFMA + 2 v_exp", w, src, out, st);
+    run<4, 3>("MFMA + 1 v_exp", w, src, out, st);
+    run<4, 4>("MFMA + 4 v_add + 1 v_cvt_pk", w, src, out, st);
+    run<4, 5>("MFMA + 2 v_add + 1 v_cvt_pk", w, src, out, st);
+    run<4, 1, 0>("no MFMA: 2 v_exp + 2 v_add + 1 v_cvt_pk", w, src, out, st);
+    run<4, 2, 0>("no MFMA: 2 v_exp", w, src, out, st);
+    run<4, 4, 0>("no MFMA: 4 v_add + 1 v_cvt_pk", w, src, out, st);
+  }
+  return 0;
+}

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned s
 }  // namespace
 
 int vittf_attention_pipe(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
-                         hipStream_t st);                                                        // attention_pipe.hip
+                         int32_t rows_per_wave, hipStream_t st);                                 // attention_pipe.hip
 
 extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads,
                                int32_t dtype, int32_t q_prescaled, void* stream) {
@@ -344,10 +344,12 @@ extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_
   const float c = 0.125f * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)stream;
   if (q_prescaled && (dtype == VITTF_BF16 || dtype == VITTF_FP16)) {
-    // default for pre-scaled q: the software-pipelined kernel (attention_pipe.hip); VITTF_ATTN_PIPE=0 keeps the
-    // round-1 lazy-maximum kernel below (read per call: the tests switch it)
+    // default for pre-scaled q: the software-pipelined kernel (attention_pipe.hip) in its 32-rows-per-wave, two-waves-per-
+    // SIMD shape (0.831 ms per launch in the pipeline); VITTF_ATTN_PIPE=2: 64 rows per wave, one wave per SIMD (0.998 ms);
+    // VITTF_ATTN_PIPE=0: the round-1 lazy-maximum kernel below (0.844 ms).  Read per call: the tests switch it.
     const char* e = getenv("VITTF_ATTN_PIPE");
-    if (!e || atoi(e) != 0) return vittf_attention_pipe(qkv, out, batch, tokens, heads, dtype, st);
+    const int pipe = e ? atoi(e) : 1;
+    if (pipe != 0) return vittf_attention_pipe(qkv, out, batch, tokens, heads, dtype, pipe == 1 ? 32 : 64, st);
   }
 #define VITTF_ATTN_LAUNCH(DTV, PREV)                                                                        \
   hipLaunchKernelGGL((attn_kernel<DTV, PREV>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,   \
