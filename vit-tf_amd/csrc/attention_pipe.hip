@@ -122,7 +122,11 @@ template <int DT> __device__ __forceinline__ void mfma32_acc(const s16x8_t& a, c
 }
 // 8-pass MFMA result -> any non-MFMA reader / writer: 12 wait states (cdna_hip_programming.md 5.7 item 2); also covers a
 // v_accvgpr_write followed by an asm MFMA
-__device__ __forceinline__ void mfma_acc_fence() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
+// The accumulators are operands of the fence: a register-only statement is ordered against other register-only code
+// through its operands alone (a "memory" clobber orders loads and stores, nothing else).
+__device__ __forceinline__ void mfma_acc_fence(f32x16_t& o0, f32x16_t& o1) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+a"(o0), "+a"(o1));
+}
 
 // step j of O^T(64 dims x 32 queries) += V^T P^T: j = 2 s2 + dvt (key step s2 feeds pf_s2, output half dvt)
 template <int DT, bool ACC>
@@ -290,7 +294,10 @@ __device__ __forceinline__ void attn_slot(const LdsBases& b, const QFrag (&q)[RB
     for (int r = 0; r < 16; ++r) zero[r] = 0.f;
     KFrag kh;
     load_k<CK_OFF>(b, kh);
-    if constexpr (RB == 2) mfma_acc_fence();      // the output accumulators are about to be rescaled by VALU code
+    if constexpr (RB == 2) {                      // the output accumulators are about to be rescaled by VALU code
+#pragma unroll
+      for (int a = 0; a < RB; ++a) mfma_acc_fence(st[a].o0, st[a].o1);
+    }
 #pragma unroll
     for (int a = 0; a < RB; ++a) {
       f32x16_t raw = score_mfma<DT>(kh, q[a], zero);
@@ -321,10 +328,118 @@ __device__ __forceinline__ void attn_slot(const LdsBases& b, const QFrag (&q)[RB
       ps[a] = psum0 + psum1;
       pack_p<DT>(p[a], pfc0[a], pfc1[a]);
     }
-    if constexpr (RB == 2) mfma_acc_fence();
+    if constexpr (RB == 2) {
+#pragma unroll
+      for (int a = 0; a < RB; ++a) mfma_acc_fence(st[a].o0, st[a].o1);
+    }
   }
 #pragma unroll
   for (int a = 0; a < RB; ++a) st[a].l_run += ps[a];
+}
+
+// The same slot with RUN-TIME ring offsets and flags, for the tiles outside the steady-state loop (the first tile, the up to
+// two tiles the 3-tile loop leaves over, the ragged last tile): executed a handful of times per workgroup, so nothing is
+// pinned or interleaved here -- what matters is that these tiles are ONE code path instead of seven template instances:
+// with seven, hipcc spilled ~110 VGPRs around their joins (276 B of scratch per lane, ~0.4 GB of extra HBM traffic per
+// launch, as much as the kernel's algorithmic traffic).
+template <int DT, int RB>
+__device__ __forceinline__ void attn_slot_rt(const LdsBases& b, const QFrag (&q)[RB], AttnState (&st)[RB], f32x16_t (&s_cur)[RB],
+                                             f32x16_t (&s_next)[RB], const KFrag& kc, const VFrag& vc, KFrag& kn, VFrag& vn,
+                                             const s16x8_t (&pfp0)[RB], const s16x8_t (&pfp1)[RB], s16x8_t (&pfc0)[RB],
+                                             s16x8_t (&pfc1)[RB], int ck_off, int nk_off, int nv_off, bool pf_k, bool do_s,
+                                             bool do_o, bool mask, int key0, int tokens, int h) {
+  constexpr float THR = DT == VITTF_FP16 ? 8192.f : 1073741824.f;
+  constexpr bool ACC = RB == 2;
+  if (pf_k) {
+    kn.k[0] = *reinterpret_cast<const s16x8_t*>(b.ka0 + nk_off);
+    kn.k[1] = *reinterpret_cast<const s16x8_t*>(b.ka1 + nk_off);
+    kn.k[2] = *reinterpret_cast<const s16x8_t*>(b.ka2 + nk_off);
+    kn.k[3] = *reinterpret_cast<const s16x8_t*>(b.ka3 + nk_off);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vn.v[i] = load_vt(b.va0, b.va1, nv_off + 2048 * (i >> 1) + 512 * (i & 1));
+  if (do_s) {
+#pragma unroll
+    for (int a = 0; a < RB; ++a) s_next[a] = score_mfma<DT>(kc, q[a], st[a].negm);
+  }
+  if (do_o) {
+#pragma unroll
+    for (int a = 0; a < RB; ++a) out_mfma<DT, ACC>(vc, pfp0[a], pfp1[a], st[a].o0, st[a].o1);
+  }
+  if (mask) {
+#pragma unroll
+    for (int a = 0; a < RB; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (key0 + acc_row(r, h) >= tokens) s_cur[a][r] = -INFINITY;
+  }
+  float p[RB][16], ps[RB];
+  float pmax = 0.f;
+#pragma unroll
+  for (int a = 0; a < RB; ++a) {
+    float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      p[a][r] = __builtin_amdgcn_exp2f(s_cur[a][r]);
+      p[a][r + 1] = __builtin_amdgcn_exp2f(s_cur[a][r + 1]);
+      psum0 += p[a][r];
+      psum1 += p[a][r + 1];
+    }
+    ps[a] = psum0 + psum1;
+    pmax = a == 0 ? ps[0] : fmaxf(pmax, ps[a]);
+  }
+  if (__builtin_expect(__any(!(pmax <= THR)), 0)) {       // slow path, as in attn_slot
+    f32x16_t zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    KFrag kh;
+    kh.k[0] = *reinterpret_cast<const s16x8_t*>(b.ka0 + ck_off);
+    kh.k[1] = *reinterpret_cast<const s16x8_t*>(b.ka1 + ck_off);
+    kh.k[2] = *reinterpret_cast<const s16x8_t*>(b.ka2 + ck_off);
+    kh.k[3] = *reinterpret_cast<const s16x8_t*>(b.ka3 + ck_off);
+    if constexpr (RB == 2) {
+#pragma unroll
+      for (int a = 0; a < RB; ++a) mfma_acc_fence(st[a].o0, st[a].o1);
+    }
+#pragma unroll
+    for (int a = 0; a < RB; ++a) {
+      f32x16_t raw = score_mfma<DT>(kh, q[a], zero);
+      if (mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + acc_row(r, h) >= tokens) raw[r] = -INFINITY;
+      }
+      const float tmax = tile_max(raw);
+      const float delta = fmaxf(tmax + st[a].negm[0], 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      st[a].l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[a].o0[r] *= alpha;
+        st[a].o1[r] *= alpha;
+        st[a].negm[r] -= delta;
+        if (do_s) s_next[a][r] -= delta;
+      }
+      float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        p[a][r] = __builtin_amdgcn_exp2f(raw[r] + st[a].negm[r]);
+        p[a][r + 1] = __builtin_amdgcn_exp2f(raw[r + 1] + st[a].negm[r + 1]);
+        psum0 += p[a][r];
+        psum1 += p[a][r + 1];
+      }
+      ps[a] = psum0 + psum1;
+    }
+    if constexpr (RB == 2) {
+#pragma unroll
+      for (int a = 0; a < RB; ++a) mfma_acc_fence(st[a].o0, st[a].o1);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < RB; ++a) {
+    st[a].l_run += ps[a];
+    pack_p<DT>(p[a], pfc0[a], pfc1[a]);
+  }
 }
 
 template <int DT, int ABL, int RB>
@@ -487,35 +602,68 @@ __global__ __launch_bounds__(256, RB == 2 ? 1 : 2) void attn_pipe_kernel(const u
     attn_slot<DT, ABL, RB, ck_, nk_, nv_, pfk_, dos_, doo_, LASTT>(b, q, st, SC, SN, KC, VC, KN, VN, PP0, PP1, PC0, PC1,  \
                                                                  t * KT + 32 * (J), tokens, h);                        \
   }
-#define PIPE_TILE(B, FIRST, LASTT)                                                                                     \
+#define PIPE_TILE(B)                                                                                                   \
   {                                                                                                                    \
-    PIPE_SLOT(B, 0, FIRST, LASTT, sA, sB, kA, vA, kB, vB, pB0, pB1, pA0, pA1)                                          \
-    PIPE_SLOT(B, 1, FIRST, LASTT, sB, sA, kB, vB, kA, vA, pA0, pA1, pB0, pB1)                                          \
+    PIPE_SLOT(B, 0, false, false, sA, sB, kA, vA, kB, vB, pB0, pB1, pA0, pA1)                                          \
+    PIPE_SLOT(B, 1, false, false, sB, sA, kB, vB, kA, vA, pA0, pA1, pB0, pB1)                                          \
     if constexpr (SLOTS == 4) {                                                                                        \
-      PIPE_SLOT(B, 2, FIRST, LASTT, sA, sB, kA, vA, kB, vB, pB0, pB1, pA0, pA1)                                        \
-      PIPE_SLOT(B, 3, FIRST, LASTT, sB, sA, kB, vB, kA, vA, pA0, pA1, pB0, pB1)                                        \
+      PIPE_SLOT(B, 2, false, false, sA, sB, kA, vA, kB, vB, pB0, pB1, pA0, pA1)                                        \
+      PIPE_SLOT(B, 3, false, false, sB, sA, kB, vB, kA, vA, pA0, pA1, pB0, pB1)                                        \
+    }                                                                                                                  \
+    ++t;                                                                                                               \
+  }
+  // the same tile through the run-time slot: ring position, first / last handling and masking decided at run time
+#define COLD_SLOT(J, SC, SN, KC, VC, KN, VN, PP0, PP1, PC0, PC1)                                                       \
+  {                                                                                                                    \
+    const int ck_ = rb_ * BUFB + 4096 * (J);                                                                           \
+    const int nk_ = ((J) + 2 < SLOTS) ? rb_ * BUFB + 4096 * ((J) + 2) : rbn_ * BUFB + 4096 * ((J) + 2 - SLOTS);        \
+    const int nv_ = rb_ * BUFB + KVB + 4096 * (J);                                                                     \
+    attn_slot_rt<DT, RB>(b, q, st, SC, SN, KC, VC, KN, VN, PP0, PP1, PC0, PC1, ck_, nk_, nv_,                           \
+                         !(last_ && (J) + 2 >= SLOTS), !(last_ && (J) + 1 >= SLOTS), !(t == 0 && (J) == 0), last_,     \
+                         t * KT + 32 * (J), tokens, h);                                                                \
+  }
+#define COLD_TILE()                                                                                                    \
+  {                                                                                                                    \
+    const int rb_ = t % NBUF, rbn_ = (rb_ + 1) % NBUF;                                                                 \
+    const bool last_ = t == nt - 1;                                                                                    \
+    COLD_SLOT(0, sA, sB, kA, vA, kB, vB, pB0, pB1, pA0, pA1)                                                           \
+    COLD_SLOT(1, sB, sA, kB, vB, kA, vA, pA0, pA1, pB0, pB1)                                                           \
+    if constexpr (SLOTS == 4) {                                                                                        \
+      COLD_SLOT(2, sA, sB, kA, vA, kB, vB, pB0, pB1, pA0, pA1)                                                         \
+      COLD_SLOT(3, sB, sA, kB, vB, kA, vA, pA0, pA1, pB0, pB1)                                                         \
     }                                                                                                                  \
     ++t;                                                                                                               \
   }
   int t = 0;
   unsigned long long stamp_c0 = 0, stamp_r0 = 0;
   if constexpr (ABL == 5) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
-  if (nt == 1) {
-    PIPE_TILE(0, true, true)
-  } else {
-    PIPE_TILE(0, true, false)
-    while (t + 3 <= nt - 1) {
-      PIPE_TILE_BARRIER(0) PIPE_TILE(1, false, false)
-      PIPE_TILE_BARRIER(1) PIPE_TILE(2, false, false)
-      PIPE_TILE_BARRIER(2) PIPE_TILE(0, false, false)
+  if constexpr (ABL == 0 || ABL == 5) {
+    COLD_TILE()                                   // tile 0 (published by the prologue barrier)
+    while (t + 3 <= nt - 1) {                     // steady state: t % 3 == 1 here
+      PIPE_TILE_BARRIER(0) PIPE_TILE(1)
+      PIPE_TILE_BARRIER(1) PIPE_TILE(2)
+      PIPE_TILE_BARRIER(2) PIPE_TILE(0)
     }
-    const int rem = (nt - 1) - t;        // 0..2 more full tiles in front of the last one; t % 3 == 1 here
-    if (rem >= 1) { PIPE_TILE_BARRIER(0) PIPE_TILE(1, false, false) }
-    if (rem >= 2) { PIPE_TILE_BARRIER(1) PIPE_TILE(2, false, false) }
-    if (rem == 0) { PIPE_TILE_BARRIER(0) PIPE_TILE(1, false, true) }
-    else if (rem == 1) { PIPE_TILE_BARRIER(1) PIPE_TILE(2, false, true) }
-    else { PIPE_TILE_BARRIER(2) PIPE_TILE(0, false, true) }
+    while (t < nt) {                              // up to two left-over tiles and the ragged last one
+      const int b2_ = (t + 2) % NBUF;
+      PIPE_TILE_BARRIER(b2_)
+      COLD_TILE()
+    }
+  } else {                                        // timing-only builds: every middle tile through the templated slot
+    COLD_TILE()
+    while (t + 3 <= nt - 1) {
+      PIPE_TILE_BARRIER(0) PIPE_TILE(1)
+      PIPE_TILE_BARRIER(1) PIPE_TILE(2)
+      PIPE_TILE_BARRIER(2) PIPE_TILE(0)
+    }
+    while (t < nt) {
+      const int b2_ = (t + 2) % NBUF;
+      PIPE_TILE_BARRIER(b2_)
+      COLD_TILE()
+    }
   }
+#undef COLD_TILE
+#undef COLD_SLOT
 #undef PIPE_TILE
 #undef PIPE_SLOT
 #undef PIPE_TILE_BARRIER
@@ -523,7 +671,10 @@ __global__ __launch_bounds__(256, RB == 2 ? 1 : 2) void attn_pipe_kernel(const u
   // the output product of the very last half step: its V fragments were fetched by the last slot (odd parity -> vA, pB)
 #pragma unroll
   for (int a = 0; a < RB; ++a) out_mfma<DT, RB == 2>(vA, pB0[a], pB1[a], st[a].o0, st[a].o1);
-  if constexpr (RB == 2) mfma_acc_fence();
+  if constexpr (RB == 2) {
+#pragma unroll
+    for (int a = 0; a < RB; ++a) mfma_acc_fence(st[a].o0, st[a].o1);
+  }
   if constexpr (ABL == 5) {
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     const int w = blockIdx.x * 4 + wave;
