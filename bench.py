@@ -333,7 +333,7 @@ def main():
     vit_ms = sum(v[0] for k, v in prof.items() if k != 'similarity')
     roofline = {
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-        'traffic': pmc_traffic(dom, args.engine_batch if my_slices >= args.engine_batch else my_slices, 'attention.hip')
+        'traffic': pmc_traffic(dom, args.engine_batch if my_slices >= args.engine_batch else my_slices, 'attention_pipe.hip')
         if (args.arch == 'vits8' and dom == 'attention') else None,
         'kernel': kernels[dom],
         'launches': int(dom_launches), 'avg_launch_ms': round(dom_ms / max(1, dom_launches), 4),

@@ -14,10 +14,18 @@ from vit_tf_amd import _lib   # noqa: E402
 TDT = {'bf16': torch.bfloat16, 'fp16': torch.float16}
 
 
-def timeit(fn, reps=10, warm=3):
+def timeit(fn, reps=10, warm=3, settle_s=float(os.environ.get('SETTLE_S', '0.4'))):
+    """Mean launch time by events on the launch stream, after `warm` calls AND at least settle_s seconds of back-to-back
+    calls: the chip's clock settles under sustained load (a 13-launch measurement from idle read 10-15 % slow)."""
+    import time
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < settle_s:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
@@ -31,7 +39,7 @@ def main():
     what = set(sys.argv[1:]) or {'attn', 'gemm', 'mlp', 'ln', 'sim'}
     lib = _lib.load()
     dev = torch.device('cuda', 0)
-    dt = os.environ.get('DT', 'bf16')
+    dt = os.environ.get('DT', 'fp16')
     batch, tokens, heads, d = int(os.environ.get('BATCH', '32')), int(os.environ.get('TOKENS', '4097')), 6, 384
     rows = batch * tokens
     g = torch.Generator(device='cpu').manual_seed(0)

@@ -34,6 +34,8 @@ for s in "$@"; do
     attnq)    step test_attnq 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider -k "attention and pipe" ;;
     benchvar) for pipe in 2 1 0; do VITTF_BENCH_OVERLAP=0 VITTF_ATTN_PIPE=$pipe step benchvar_pipe$pipe 600 python bench.py --workload 256 --cpu-slices 0 --steps 3; done ;;
     ceiling)  step ceiling 240 tools/micro/mfma_ceiling ;;
+    pmcattn)  step pmc_attn 900 bash tools/pmc_attn.sh attn ;;
+    pmcsim)   step pmc_sim 600 bash tools/pmc_sim.sh ;;
     bench512) step bench512 900 python bench.py ;;
     prof512)  cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               export VITTF_BENCH_OVERLAP=0

@@ -1,9 +1,10 @@
 #!/usr/bin/env bash
 # PMC passes over the attention microbench (counters only with --kernel-trace; separate runs per counter set).
 set -u
+export SETTLE_S=0.05   # (bench_kernels.py: no clock-settling loop under the profiler)
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/pmc
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 WHAT=${1:-attn}
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \

@@ -1,9 +1,10 @@
 #!/usr/bin/env bash
 # PMC passes (HBM bytes) over the similarity microbench: FETCH_SIZE / WRITE_SIZE in separate runs, --kernel-trace only.
 set -u
+export SETTLE_S=0.05   # (bench_kernels.py: no clock-settling loop under the profiler)
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/pmc_sim
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; do
   i=$((i+1))

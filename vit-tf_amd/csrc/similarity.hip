@@ -152,9 +152,22 @@ __global__ __launch_bounds__(256) void transpose_queries(const float* __restrict
   qf_t[e] = a < n_ann ? qf[(int64_t)(a0 + a) * f + ff] : 0.f;
 }
 
+// sqrtf for NORMAL positive x, correctly rounded: v_sqrt_f32 (1 ulp) + the library's own correction step (try the two
+// neighbours, keep the one whose square brackets x) without its scaling of denormal inputs -- the same bits as sqrtf for
+// every x the threshold lets through, a third of the instructions and none of the per-element condition masks that made
+// 64 inlined sqrtf calls spill 140-190 registers at this kernel's 128-VGPR budget.
+__device__ __forceinline__ float sqrt_cr_normal(float x) {
+  float y = __builtin_amdgcn_sqrtf(x);
+  const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+  const float rm = fmaf(-ym, y, x), rp = fmaf(-yp, y, x);
+  y = rm <= 0.f ? ym : y;
+  y = rp > 0.f ? yp : y;
+  return y;
+}
+
 __device__ __forceinline__ float thresh_pow(float s) {
   // where(s >= 0.25, s, 0) ** 2.5   (predict_ntf.py:71)
-  return s >= 0.25f ? s * s * sqrtf(s) : 0.f;
+  return s >= 0.25f ? s * s * sqrt_cr_normal(s) : 0.f;
 }
 
 // ACT 0: where(s >= 0.25, s, 0) ** 2.5 (predict_ntf.py:71);  ACT 1: clamp(s, 0, 1) ** expo (infer.py:104, resample_topk)
@@ -182,37 +195,49 @@ __device__ __forceinline__ void sim_finish(float (&acc)[ACH][NV], int64_t v0, in
   // per-class reduction over the chunk's annotations: they are sorted by class, so a running sum in annotation order is
   // handed over whenever the next annotation belongs to another class (wave-uniform branches: the activation is
   // evaluated once per value and at most nc hand-overs run)
-  float run[NV];
+  // the activation first, in place (the same for every class)
+  if constexpr (!BIG) {
 #pragma unroll
-  for (int j = 0; j < NV; ++j) run[j] = 0.f;
+    for (int a = 0; a < ACH; ++a)
 #pragma unroll
-  for (int a = 0; a < ACH; ++a) {      // (fully unrolled: acc must keep static indices; padding queries are zero and add 0)
+      for (int j = 0; j < NV; ++j) acc[a][j] = activate<ACT>(acc[a][j], expo);
+  }
+  // per-class reduction over the chunk's annotations, one class per trip of a RUN-TIME loop: the annotations are sorted by
+  // class, so class c's values are summed in annotation order by skipping the others (wave-uniform scalar branches; acc
+  // keeps static indices).  One copy of the hand-over code instead of sixteen: the unrolled form kept ~170 VGPRs and 22
+  // SGPRs in scratch around its branches (23 MB of scratch writes per pass: profiles/r02b_similarity_pmc.txt).
+  for (int c = 0; c < ch.nc; ++c) {
+    float run[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) run[j] += BIG ? acc[a][j] : activate<ACT>(acc[a][j], expo);
-    const bool hand_over = a < ch.n_ann && (a + 1 == ch.n_ann || (a + 1 < ACH && ch.cls[a + 1 < ACH ? a + 1 : a] != ch.cls[a]));
-    if (hand_over) {                   // wave-uniform
-      const int c = ch.cls[a];
-      float* dst = sim + (int64_t)(ch.c0 + c) * nvox + v0;
-      float m = 0.f;
+    for (int j = 0; j < NV; ++j) run[j] = 0.f;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        if (v0 + j < nvox) {
-          float t = run[j];
-          if (!ch.first[c]) t += dst[j];
-          if (ch.last[c]) {
-            t = t / ch.count[c];                // mean = sum / count (predict_ntf.py:72 / :63), true division
-            if (BIG) t = activate<ACT>(t, expo);
-            m = fmaxf(m, t);
-          }
-          dst[j] = t;
+    for (int a = 0; a < ACH; ++a) {
+      if (ch.cls[a] == c) {            // (padding annotations carry class -1)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) run[j] += acc[a][j];
+      }
+    }
+    float* dst = sim + (int64_t)(ch.c0 + c) * nvox + v0;
+    const bool first = ch.first[c] != 0, last = ch.last[c] != 0;
+    const float count = ch.count[c];
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      if (v0 + j < nvox) {
+        float t = run[j];
+        if (!first) t += dst[j];
+        if (last) {
+          t = t / count;                      // mean = sum / count (predict_ntf.py:72 / :63), true division
+          if (BIG) t = activate<ACT>(t, expo);
+          m = fmaxf(m, t);
         }
-        run[j] = 0.f;
+        dst[j] = t;
       }
-      if (ch.last[c]) {   // sims are >= 0, so the uint bit pattern orders like the float: one atomicMax per wave and class
+    }
+    if (last) {   // sims are >= 0, so the uint bit pattern orders like the float: one atomicMax per wave and class
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxbits + ch.c0 + c, __float_as_uint(m));
-      }
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxbits + ch.c0 + c, __float_as_uint(m));
     }
   }
 }
@@ -306,9 +331,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define SIM_PART_PUT(SLOT)                                                                   \
   _Pragma("unroll") for (int a = 0; a < ACH; ++a)                                            \
       _Pragma("unroll") for (int j = 0; j < SVPT; ++j) part[SLOT][a * SVPT + j][lane] = acc[a][j];
+  // (adds in groups of four annotations behind scheduling fences: with all 64 LDS reads hoisted in front of the adds, 64
+  // temporaries + 64 accumulators filled the 128-VGPR budget and ~170 registers went to scratch in wave 0's finish)
 #define SIM_PART_ADD(SLOT)                                                                   \
-  _Pragma("unroll") for (int a = 0; a < ACH; ++a)                                            \
-      _Pragma("unroll") for (int j = 0; j < SVPT; ++j) acc[a][j] += part[SLOT][a * SVPT + j][lane];
+  _Pragma("unroll") for (int a = 0; a < ACH; ++a) {                                          \
+    _Pragma("unroll") for (int j = 0; j < SVPT; ++j) acc[a][j] += part[SLOT][a * SVPT + j][lane]; \
+    if ((a & 3) == 3) __builtin_amdgcn_sched_barrier(0);                                     \
+  }
   // (every wave reaches all three barriers)
   if (wave >= 2) SIM_PART_PUT(wave - 2)
   __syncthreads();
