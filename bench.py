@@ -51,6 +51,8 @@ def parse_args():
                     help='MFMA operand type: fp16 (default; parity tests assert 1e-3) or bf16 (2.4e-3 .. 3.9e-3)')
     ap.add_argument('--arch', type=str, default='vits8', choices=['vits8', 'vitb8'],
                     help="vits8 = the BASELINE metric's model; vitb8 = configs[3]'s feature extractor (D = 768), informative")
+    ap.add_argument('--attention', type=str, default='16bit', choices=['16bit', 'fp8'],
+                    help="fp8 = BASELINE configs[3]'s fp8 MFMA attention path (informative: ~3e-2 on the features, not the contract dtype)")
     ap.add_argument('--engine-batch', type=int, default=32)
     ap.add_argument('--cpu-slices', type=int, default=5, help='slices timed for the CPU baseline (0 = skip)')
     return ap.parse_args()
@@ -214,7 +216,7 @@ def main():
     vol, label, desc = make_workload(args.workload, vt)
     desc = desc.replace('ViT-S/8', 'ViT-B/8 (D = 768)') if args.arch == 'vitb8' else desc
     sd = vt.synthetic_state_dict(args.arch, 0)
-    model = vt.HipViT(sd, args.arch, args.dtype, device=dev)
+    model = vt.HipViT(sd, args.arch, args.dtype, device=dev, attention=args.attention)
     dim, depth, heads, patch = vt.ARCHS[args.arch]
     dvol = vt.DeviceVolume(vol, dev)                     # the input is resident in HBM before the timed region
     ann = query_voxels(label)
@@ -321,7 +323,7 @@ def main():
     if prof['mlp'][1] > 0:          # fused MLP: fc1 + fc2 in one kernel
         flop_slice['mlp'] = flop_slice.pop('gemm_fc1') + flop_slice.pop('gemm_fc2')
     flops = {k: v * slices_done for k, v in flop_slice.items()}
-    kernels = {'attention': f'attn_kernel<{args.dtype}>', 'gemm_qkv': f'gemm_ws_kernel<{args.dtype}, qkv>',
+    kernels = {'attention': ('attn_fp8_kernel (+ absmax + quantise)' if args.attention == 'fp8' else f'attn_pipe_kernel<{args.dtype}>'), 'gemm_qkv': f'gemm_ws_kernel<{args.dtype}, qkv>',
                'gemm_fc1': f'gemm_ws_kernel<{args.dtype}, fc1+gelu>', 'gemm_proj': f'gemm_rows_kernel<{args.dtype}, proj+ln>',
                'gemm_fc2': f'gemm_rows_kernel<{args.dtype}, fc2+ln>', 'gemm': f'gemm_kernel<{args.dtype}, kfeat>',
                'mlp': f'mlp_kernel<{args.dtype}>', 'patch_embed': 'patch_embed_kernel', 'layernorm': 'layernorm_kernel'}
@@ -334,7 +336,7 @@ def main():
     roofline = {
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
         'traffic': pmc_traffic(dom, args.engine_batch if my_slices >= args.engine_batch else my_slices, 'attention_pipe.hip')
-        if (args.arch == 'vits8' and dom == 'attention') else None,
+        if (args.arch == 'vits8' and dom == 'attention' and args.attention == '16bit') else None,
         'kernel': kernels[dom],
         'launches': int(dom_launches), 'avg_launch_ms': round(dom_ms / max(1, dom_launches), 4),
         'flop_per_launch': flops[dom] / max(1, dom_launches),
@@ -351,7 +353,8 @@ def main():
             'value': round(args.steps * total_slices / elapsed, 2),
             'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
-            'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None,
+            'dtype': args.dtype if args.attention == '16bit' else f'{args.dtype} (attention operands fp8 e4m3)', 'data': 'synthetic',
             'rccl_ranks': torch.distributed.get_world_size() if world > 1 else 1,
             'config': {'workload': desc, 'volume': list(dvol.shape), 'slices_per_step': total_slices,
                        'image': [im_sz[0], im_sz[1]], 'tokens': n_tokens, 'feature_volume': [dim, *feat_out],

@@ -58,6 +58,8 @@ typedef struct vittf_vit_config {
   int32_t patch;       /* P: 8 */
   int32_t dtype;       /* vittf_dtype of the MFMA operands */
   float   ln_eps;      /* 1e-6 */
+  int32_t attention_fp8; /* 0: 16-bit attention (default).  1: the fp8 (e4m3) block-scaled MFMA attention path of BASELINE
+                            configs[3] (vittf_attention_fp8): 3-mantissa-bit operands, ~3e-2 on the features -- opt-in */
 } vittf_vit_config;
 
 /* All weights live in HBM for the lifetime of the engine (about 43 MB for ViT-S).  Per-layer tensors
@@ -207,6 +209,15 @@ int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, i
  * clock and 100 MHz real-time stamps the first waves took around their key loop: out_host[wave][4] = {clock start, clock
  * end, real-time start, real-time end}.  Synchronises the device; returns the number of waves copied (<= max_waves). */
 int vittf_debug_attention_stamps(uint64_t* out_host, int32_t max_waves);
+
+/* fp8 attention (BASELINE configs[3]: "ViT-B/8 features, fp8 MFMA attention path").  Same contract as vittf_attention with
+ * q_prescaled = 1, computed with OCP e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4: per (slice, head) power-of-two
+ * scales for q, k and v (absmax / 448, applied by the instruction's scale operands), fp32 softmax statistics and
+ * accumulators, P as fp8.  Error of the attention output ~3e-2 relative (3-bit mantissas):
+ * an opt-in, never the default.  ws: vittf_attention_fp8_workspace_bytes(batch, tokens, heads) bytes, 256-byte aligned. */
+size_t vittf_attention_fp8_workspace_bytes(int32_t batch, int32_t tokens, int32_t heads);
+int vittf_attention_fp8(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype, void* ws,
+                        size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Feature-volume epilogue (infer.py:201-203 permute_out, :329 AdaptiveAvgPool3d, :330-332 axis sum).

@@ -61,7 +61,7 @@ def norm_mean_std(t, mu=0, std=1):
 
 
 # ---------------------------------------------------------------------------- model (:42-46, :239-264)
-_MODEL_OPTS = {'weights': None, 'synthetic_seed': None, 'dtype': 'fp16'}
+_MODEL_OPTS = {'weights': None, 'synthetic_seed': None, 'dtype': 'fp16', 'attention': '16bit'}
 
 
 def get_dino_model(name):
@@ -80,7 +80,7 @@ def get_dino_model(name):
         print(f'No local checkpoint for dino_{name}: pass --weights PATH (DINO state dict) or '
               f'--synthetic-weights SEED. This build never downloads weights.')
         sys.exit(1)
-    return vt.HipViT(sd, name, dtype=_MODEL_OPTS['dtype'])
+    return vt.HipViT(sd, name, dtype=_MODEL_OPTS['dtype'], attention=_MODEL_OPTS['attention'])
 
 
 def get_dinov2_model(name):
@@ -261,12 +261,14 @@ def main(argv=None):
     parser.add_argument('--synthetic-weights', type=int, default=None, metavar='SEED', help='Use seeded synthetic weights')
     parser.add_argument('--engine-dtype', type=str, choices=['fp16', 'bf16'], default='fp16',
                         help='MFMA operand type (fp16 = the reference GPU autocast type, 1e-3 parity; bf16 opt-in)')
+    parser.add_argument('--attention', type=str, choices=['16bit', 'fp8'], default='16bit',
+                        help="fp8: e4m3 attention on the block-scaled matrix instruction (BASELINE configs[3]; ~3e-2 on the features)")
     args = parser.parse_args(argv)
 
     if args.cpu:
         print('--cpu: this build has no CPU path (the hot path runs only on MI355X / gfx950).')
         sys.exit(1)
-    _MODEL_OPTS.update(weights=args.weights, synthetic_seed=args.synthetic_weights, dtype=args.engine_dtype)
+    _MODEL_OPTS.update(weights=args.weights, synthetic_seed=args.synthetic_weights, dtype=args.engine_dtype, attention=args.attention)
     dino_model, dino_model_fn, patch_size = load_model(args)
     rank, world = _init_distributed()
     cache_path = _agree_on_output_path(args, rank, world)

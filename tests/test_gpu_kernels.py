@@ -885,3 +885,50 @@ def test_similarity_single_annotation(gpu, f, n):
     d = torch.minimum(d, 256 - d)
     assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01
     assert np.array_equal(vt.assign_labels(got), osim.assign_labels([got['ntf1']]))
+
+
+# ---------------------------------------------------------------- fp8 attention (BASELINE configs[3])
+def _e4m3(x):
+    """Round to OCP e4m3 (torch.float8_e4m3fn) and back: the host-side model of the kernel's operand rounding."""
+    return x.to(torch.float8_e4m3fn).to(torch.float64)
+
+
+@pytest.mark.parametrize('dt', ['fp16', 'bf16'])
+@pytest.mark.parametrize('batch,tokens,heads', [(1, 1, 2), (2, 65, 2), (1, 200, 12), (2, 577, 2), (1, 4097, 2)])
+def test_attention_fp8(gpu, dt, batch, tokens, heads):
+    """vittf_attention_fp8 (e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4, per-head power-of-two scales, fp32 softmax
+    statistics) against (a) the exact fp64 attention of the same 16-bit inputs -- the stated tolerance of the path: 6e-2
+    relative Frobenius, 3-bit mantissas on q, k, v and P -- and (b) a host model that rounds q, k, v to e4m3 with the same
+    scales and computes the rest in fp64 -- 2e-2: what is left is the rounding of P and of the output."""
+    lib = _lib.load()
+    g = gen(tokens + heads)
+    d = heads * 64
+    qkv = torch.randn(batch * tokens, 3 * d, generator=g)
+    qkv[:, :2 * d] *= 1.3
+    qkv[:, 2 * d:] = qkv[:, 2 * d:] * 2.0 + 0.5                # v with an offset and its own range
+    qkv = _prescale(qkv, heads, dt)
+    qd = qkv.to(gpu)
+    out = torch.full((batch * tokens + 2, d), 7.0, dtype=TDT[dt], device=gpu)
+    ws = torch.empty(lib.vittf_attention_fp8_workspace_bytes(batch, tokens, heads), dtype=torch.uint8, device=gpu)
+    _lib.check(lib.vittf_attention_fp8(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().double()
+    assert (got[batch * tokens:] == 7.0).all(), 'wrote past the last row'
+    got = got[:batch * tokens]
+    assert torch.isfinite(got).all()
+    exact = _attn_ref(qkv, batch, tokens, heads, 1)
+    x = qkv.double().view(batch, tokens, 3, heads, 64)
+    xq = torch.empty_like(x)
+    for part in range(3):                                       # per (slice, head) power-of-two scale: amax * 2^-e <= 448
+        t = x[:, :, part]                                       # (batch, tokens, heads, 64)
+        amax = t.abs().amax(dim=(1, 3), keepdim=True).clamp_min(1e-30)
+        e = torch.ceil(torch.log2(amax / 448.0))
+        e = torch.where(torch.log2(amax / 448.0) == e, e + 1, e)       # frexp convention: mantissa in [0.5, 1)
+        xq[:, :, part] = _e4m3(t / 2.0 ** e) * 2.0 ** e
+    model = _attn_ref(xq.reshape(batch * tokens, 3 * d), batch, tokens, heads, 1)
+    e_exact, e_model = rel_fro(got, exact), rel_fro(got, model)
+    print(f'fp8 attention {batch}x{tokens}x{heads} {dt}: rel fro {e_exact:.3e} vs exact, {e_model:.3e} vs the e4m3-operand model')
+    assert e_exact <= 6e-2 and e_model <= 2e-2
+    assert lib.vittf_attention_fp8(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], _lib.ptr(ws), 16,
+                                   _lib.stream_ptr()) == -2      # workspace too small

@@ -315,6 +315,13 @@ def test_vitb8_full_size_slice(gpu):
         e = rel_fro(got, ref)
         print(f'vitb8 N=4097 {dt}: rel fro {e:.3e}')
         assert e <= TOL[dt][0]
+    # BASELINE configs[3]: the same slice with the fp8 (e4m3, block-scaled MFMA) attention path.  Its own stated tolerance:
+    # 5e-2 relative Frobenius on the K features (3-bit mantissas on q, k, v and P in 11 attention layers)
+    model = vt.HipViT(sd, 'vitb8', 'fp16', attention='fp8')
+    got = vt.k_slices(model, vt.DeviceVolume(vol, gpu), 'y', im_sz, 31, 32).cpu()
+    e = rel_fro(got, ref)
+    print(f'vitb8 N=4097 fp16 + fp8 attention: rel fro {e:.3e}')
+    assert torch.isfinite(got.float()).all() and e <= 5e-2
 
 
 def test_fos128_long_sequence(gpu):

@@ -54,6 +54,18 @@ def main():
         ms = timeit(lambda: _lib.check(lib.vittf_attention(_lib.ptr(qkv), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], pre, _lib.stream_ptr())))
         fl = batch * 4 * tokens * tokens * d
         print(f'attention  (q_prescaled={pre}) batch {batch} N {tokens}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({fl / ms / 1e9 / 25:.1f} % of 2.5 PF)')
+    if 'attn8' in what:      # the fp8 attention path (absmax + quantise + attention), ViT-S and ViT-B head counts
+        for hh in (6, 12):
+            qkv = torch.randn(rows, 3 * hh * 64, generator=g)
+            qkv[:, :2 * hh * 64] *= 1.5
+            qkv[:, :hh * 64] *= 0.125 * 1.4426950408889634
+            qkv = qkv.to(TDT[dt]).to(dev)
+            out = torch.empty(rows, hh * 64, dtype=TDT[dt], device=dev)
+            ws = torch.empty(lib.vittf_attention_fp8_workspace_bytes(batch, tokens, hh), dtype=torch.uint8, device=dev)
+            ms = timeit(lambda: _lib.check(lib.vittf_attention_fp8(_lib.ptr(qkv), _lib.ptr(out), batch, tokens, hh, _lib.DTYPES[dt], _lib.ptr(ws), ws.numel(), _lib.stream_ptr())))
+            fl = batch * 4 * tokens * tokens * hh * 64
+            ms16 = timeit(lambda: _lib.check(lib.vittf_attention(_lib.ptr(qkv), _lib.ptr(out), batch, tokens, hh, _lib.DTYPES[dt], 1, _lib.stream_ptr())))
+            print(f'attention fp8 ({hh} heads) batch {batch} N {tokens}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s;  16-bit kernel on the same tensors: {ms16:.3f} ms')
     if 'gemm' in what:
         for name, n, k, epi in (('qkv', 3 * d, d, 0), ('qkv+qscale', 3 * d, d, 4), ('proj+res', d, d, 2), ('fc1+gelu', 4 * d, d, 1), ('fc2+res', d, 4 * d, 2), ('kfeat', d, d, 3)):
             a = torch.randn(rows, k, generator=g).to(TDT[dt]).to(dev)

@@ -36,6 +36,11 @@ for s in "$@"; do
     ceiling)  step ceiling 240 tools/micro/mfma_ceiling ;;
     pmcattn)  step pmc_attn 900 bash tools/pmc_attn.sh attn ;;
     pmcsim)   step pmc_sim 600 bash tools/pmc_sim.sh ;;
+    fp8)      step test_fp8 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -q -m gpu -s -p no:cacheprovider -k "fp8 or vitb8" ;;
+    benchb)   for a in 16bit fp8; do VITTF_BENCH_OVERLAP=0 step benchb_$a 600 python bench.py --arch vitb8 --workload 64 --attention $a --cpu-slices 0 --steps 2; done ;;
+    simtests) step test_sim 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider -k "similarity or sim or golden or labels or cosine or topk" ;;
+    prof8)    cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
+              SETTLE_S=0.05 step prof8 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof8 -- python tools/bench_kernels.py attn8 ;;
     bench512) step bench512 900 python bench.py ;;
     prof512)  cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               export VITTF_BENCH_OVERLAP=0

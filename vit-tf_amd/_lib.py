@@ -17,7 +17,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_KFEAT, EPI_BIAS_QKV = 0, 1, 2, 3
 
 class VitConfig(C.Structure):
     _fields_ = [('embed_dim', C.c_int32), ('depth', C.c_int32), ('heads', C.c_int32), ('patch', C.c_int32),
-                ('dtype', C.c_int32), ('ln_eps', C.c_float)]
+                ('dtype', C.c_int32), ('ln_eps', C.c_float), ('attention_fp8', C.c_int32)]
 
 
 class VitWeights(C.Structure):
@@ -69,6 +69,8 @@ SIGNATURES = {
     'vittf_mlp_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vittf_debug_attention_stamps': (C.c_int, [_P(C.c_uint64), _i32]),
+    'vittf_attention_fp8_workspace_bytes': (_sz, [_i32, _i32, _i32]),
+    'vittf_attention_fp8': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     'vittf_pool_slices': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64,
                                     _i64, _vp]),
     'vittf_assemble_sum': (C.c_int, [_vp, _vp, _vp, _i32, _P(_i32), _i32, _i32, _i32, _i32, _vp, _vp]),

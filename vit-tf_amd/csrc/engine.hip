@@ -34,10 +34,10 @@ hipEvent_t prof_event() {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-  size_t x, h, qkv, o, total;
+  size_t x, h, qkv, o, fp8, fp8_bytes, total;
 };
 
-WsLayout ws_layout(int d, int64_t rows) {
+WsLayout ws_layout(int d, int64_t rows, size_t fp8_bytes = 0) {
   const int64_t rp = (rows + 127) / 128 * 128;
   WsLayout l;
   size_t off = 0;
@@ -45,6 +45,7 @@ WsLayout ws_layout(int d, int64_t rows) {
   l.h = off;   off += align256((size_t)rp * d * 2);
   l.qkv = off; off += (size_t)rp * 3 * d * 2;   // QKV and O contiguous: together the [rows][4D] hidden buffer
   l.o = off;   off += align256((size_t)rp * d * 2);
+  l.fp8 = off; l.fp8_bytes = fp8_bytes; off += align256(fp8_bytes);     // operands of the fp8 attention path (opt-in)
   l.total = off;
   return l;
 }
@@ -96,7 +97,8 @@ extern "C" int vittf_device_count(void) {
 
 extern "C" size_t vittf_vit_workspace_bytes(const vittf_vit_config* cfg, int32_t batch, int32_t tokens) {
   if (!config_ok(cfg) || batch <= 0 || tokens <= 1) return 0;
-  return ws_layout(cfg->embed_dim, (int64_t)batch * tokens).total;
+  return ws_layout(cfg->embed_dim, (int64_t)batch * tokens,
+                   cfg->attention_fp8 ? vittf_attention_fp8_workspace_bytes(batch, tokens, cfg->heads) : 0).total;
 }
 
 extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit_weights* w, const vittf_pos_embed* pos,
@@ -111,7 +113,7 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   if (view->out_rows % p || view->out_cols % p) return VITTF_ERR_INVALID_ARG;
   const int tokens = (view->out_rows / p) * (view->out_cols / p) + 1;
   const int64_t rows = (int64_t)batch * tokens;
-  const WsLayout lay = ws_layout(d, rows);
+  const WsLayout lay = ws_layout(d, rows, cfg->attention_fp8 ? vittf_attention_fp8_workspace_bytes(batch, tokens, cfg->heads) : 0);
   if (ws_bytes < lay.total) return VITTF_ERR_WORKSPACE;
   if (((uintptr_t)ws & 255) != 0) return VITTF_ERR_INVALID_ARG;
   char* base = (char*)ws;
@@ -161,7 +163,10 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
                         pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, 0, dt, stream); }
     if (rc) return rc;
     { ProfScope ps(VITTF_KERNEL_ATTENTION, stream);
-      rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, pre, stream); }
+      if (cfg->attention_fp8 && pre)
+        rc = vittf_attention_fp8(QKV, O, batch, tokens, cfg->heads, dt, base + lay.fp8, lay.fp8_bytes, stream);
+      else
+        rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, pre, stream); }
     if (rc) return rc;
     { ProfScope ps(VITTF_KERNEL_GEMM_PROJ, stream);
       if (res_ln)

@@ -31,10 +31,11 @@ class HipViT:
     state_dict: DINO-layout tensors (fp32, CPU or GPU).  arch: DINO name ('vits8', ...) or
     (embed_dim, depth, heads, patch).  dtype of the MFMA operands: 'fp16' (default: the reference's own GPU autocast
     type, infer.py:309; meets the 1e-3 parity bound against the fp32 CPU path) or 'bf16' (opt-in: 8-bit mantissa,
-    2.4e-3 .. 3.9e-3 against the CPU path).
+    2.4e-3 .. 3.9e-3 against the CPU path).  attention: '16bit' (default) or 'fp8' -- BASELINE configs[3]'s fp8 MFMA
+    attention path (e4m3 operands on the block-scaled matrix instruction; ~3e-2 on the features: opt-in).
     """
 
-    def __init__(self, state_dict, arch='vits8', dtype='fp16', device=None, fused_mlp=None):
+    def __init__(self, state_dict, arch='vits8', dtype='fp16', device=None, fused_mlp=None, attention='16bit'):
         self.lib = _lib.require_device()
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         dim, depth, heads, patch = arch_of(arch)
@@ -44,7 +45,10 @@ class HipViT:
         self.dtype_id = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
         self.dtype_name = 'bf16' if self.dtype_id == _lib.BF16 else 'fp16'
         self.blocks = [_Block(heads) for _ in range(depth)]    # duck-typing of model.blocks[-1].attn.num_heads
-        self.cfg = _lib.VitConfig(dim, depth, heads, patch, self.dtype_id, 1e-6)
+        if attention not in ('16bit', 'fp8'):
+            raise ValueError(f"attention must be '16bit' or 'fp8', got {attention!r}")
+        self.attention = attention
+        self.cfg = _lib.VitConfig(dim, depth, heads, patch, self.dtype_id, 1e-6, 1 if attention == 'fp8' else 0)
 
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         h16 = _TORCH_DT[self.dtype_id]
