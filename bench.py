@@ -53,7 +53,7 @@ def parse_args():
                     help="vits8 = the BASELINE metric's model; vitb8 = configs[3]'s feature extractor (D = 768), informative")
     ap.add_argument('--attention', type=str, default='16bit', choices=['16bit', 'fp8'],
                     help="fp8 = BASELINE configs[3]'s fp8 MFMA attention path (informative: ~3e-2 on the features, not the contract dtype)")
-    ap.add_argument('--engine-batch', type=int, default=32)
+    ap.add_argument('--engine-batch', type=int, default=None, help='slices per engine call (default: extract.DEFAULT_ENGINE_BATCH)')
     ap.add_argument('--cpu-slices', type=int, default=5, help='slices timed for the CPU baseline (0 = skip)')
     return ap.parse_args()
 
@@ -117,15 +117,16 @@ def kernel_source_hash(name):
 def pmc_traffic(kernel_class, batch, source):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC pass (profiles/pmc_*.json: FETCH_SIZE doubled
     as MI355X_MICROARCH.md prescribes for gfx950 wide reads + WRITE_SIZE, separate passes).  The counters cannot be
-    collected from inside this process; null when no pass is on file for this shape AND this very kernel source."""
+    collected from inside this process; null when no pass is on file for this very kernel source.  A launch works on
+    independent slices (queries), so the bytes of a pass taken at another batch size scale linearly with it."""
     path = os.path.join(ROOT, 'profiles', f'pmc_{kernel_class}.json')
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if rec.get('batch') != batch or rec.get('source_sha1') != kernel_source_hash(source):
+    if not rec.get('batch') or rec.get('source_sha1') != kernel_source_hash(source):
         return None
-    return rec.get('hbm_bytes_per_launch')
+    return int(rec['hbm_bytes_per_launch'] * batch / rec['batch'])
 
 
 def host_cores():
@@ -216,6 +217,8 @@ def main():
     vol, label, desc = make_workload(args.workload, vt)
     desc = desc.replace('ViT-S/8', 'ViT-B/8 (D = 768)') if args.arch == 'vitb8' else desc
     sd = vt.synthetic_state_dict(args.arch, 0)
+    if args.engine_batch is None:
+        args.engine_batch = vt.extract.DEFAULT_ENGINE_BATCH
     model = vt.HipViT(sd, args.arch, args.dtype, device=dev, attention=args.attention)
     dim, depth, heads, patch = vt.ARCHS[args.arch]
     dvol = vt.DeviceVolume(vol, dev)                     # the input is resident in HBM before the timed region

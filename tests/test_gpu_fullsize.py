@@ -59,9 +59,10 @@ def _whole_volume_checks(gpu, vits8, oracle, vol, windows):
     feats = vt.feature_volume(None, model, 64, 'all', 32, dvol=dvol)
     assert feats.shape == (384, 64, 64, 64) and feats.dtype == torch.float16
     assert bool(torch.isfinite(feats).all())
-    again = vt.feature_volume(None, model, 64, 'all', 31, dvol=dvol)        # another batching of the same slices
-    assert torch.equal(feats, again), 'bits depend on the engine batch'
-    del again
+    for eb in (31, vt.extract.DEFAULT_ENGINE_BATCH):                        # other batchings of the same slices
+        again = vt.feature_volume(None, model, 64, 'all', eb, dvol=dvol)
+        assert torch.equal(feats, again), f'bits depend on the engine batch ({eb} vs 32)'
+        del again
     pooled = {ax: vt.pooled_axis(None, model, ax, im_sz, feat_out, 32, dvol=dvol) for ax in 'zyx'}
     total = (pooled['z'] + pooled['y']) + pooled['x']                        # fp16 adds, one rounding each (infer.py:330-332)
     assert torch.equal(total, feats), 'z -> y -> x fp16 sum of the pooled axes does not reproduce the volume'

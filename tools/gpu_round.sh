@@ -41,6 +41,7 @@ for s in "$@"; do
     simtests) step test_sim 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider -k "similarity or sim or golden or labels or cosine or topk" ;;
     prof8)    cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               SETTLE_S=0.05 step prof8 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof8 -- python tools/bench_kernels.py attn8 ;;
+    benchbatch) for eb in 64 128 256 512; do VITTF_BENCH_OVERLAP=0 step benchbatch_$eb 600 python bench.py --engine-batch $eb --cpu-slices 0 --steps 2; done ;;
     bench512) step bench512 900 python bench.py ;;
     prof512)  cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               export VITTF_BENCH_OVERLAP=0

@@ -18,7 +18,11 @@ from . import _lib
 
 # axis -> (sliced volume dim, (volume dim of image rows, volume dim of image cols))      infer.py:138-147
 AXIS_DIMS = {'z': (2, (0, 1)), 'y': (1, (0, 2)), 'x': (0, (1, 2))}
-DEFAULT_ENGINE_BATCH = 32
+# Slices per vittf_vit_k_features call.  Slices are independent and results do not depend on the batching (tested: 31 / 32 /
+# 256 give the same bits); larger batches amortise every launch's partial last round of workgroups (the 32 CLS rows of a
+# 32-slice batch cost the whole-row GEMMs a third round): 512^3 workload 1828 / 1852 / 1870 / 1879 / 1902 / 1906 slices/s at
+# batch 32 / 31 / 64 / 128 / 256 / 512 on one box.  256 slices = 5.6 GB of workspace (of 288 GB).
+DEFAULT_ENGINE_BATCH = 256
 # Batches of slices are independent, so consecutive batches can go round-robin onto several HIP streams (each with
 # its own workspace): the VALU/MFMA-bound attention of one batch then overlaps the HBM-bound LayerNorm / GEMM
 # epilogues of another and covers the under-filled last wave of workgroups of every launch.  Measured +5.9 % slices/s
