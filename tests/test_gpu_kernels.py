@@ -932,3 +932,13 @@ def test_attention_fp8(gpu, dt, batch, tokens, heads):
     assert e_exact <= 6e-2 and e_model <= 2e-2
     assert lib.vittf_attention_fp8(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], _lib.ptr(ws), 16,
                                    _lib.stream_ptr()) == -2      # workspace too small
+
+
+def test_non_finite_volume_is_refused(gpu):
+    vol = torch.rand((8, 8, 8), generator=gen(1))
+    vol[3, 4, 5] = float('nan')
+    with pytest.raises(ValueError):
+        vt.DeviceVolume(vol, gpu)
+    vol[3, 4, 5] = float('inf')
+    with pytest.raises(ValueError):
+        vt.DeviceVolume(vol.half(), gpu)

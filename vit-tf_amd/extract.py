@@ -70,6 +70,10 @@ class DeviceVolume:
             del raw
         else:
             self.data = vol.to(device=device, dtype=torch.float32).contiguous()
+        if not bool(torch.isfinite(self.data).all()):
+            # the attention kernels are built without NaN handling (scores are never NaN for finite input): refuse loudly
+            # instead of returning a feature volume of garbage
+            raise ValueError('volume contains NaN or Inf voxels')
         self.minmax = torch.empty(2, dtype=torch.float32, device=device)
         ws = torch.empty(lib.vittf_minmax_workspace_bytes(), dtype=torch.uint8, device=device)
         _lib.check(lib.vittf_volume_minmax(_lib.ptr(self.data), self.data.numel(), _lib.ptr(self.minmax), _lib.ptr(ws),
