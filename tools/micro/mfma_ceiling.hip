@@ -18,7 +18,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // NACC independent accumulators, FILL = 0: bare MFMAs, 1: + the softmax VALU mix per MFMA (on values that do not
 // depend on the MFMA results of this iteration), DEP = 1: a dependent chain on one accumulator
-template <int NACC, int FILL, int MFMA = 1>
+// LDSOP = 1: the A operand of every MFMA comes from LDS (ds_read_b128 of a conflict-free image, issued one MFMA ahead into
+// the other of two register sets) instead of staying in registers; LDSOP = 2: additionally two ds_read_b64_tr_b16 per second
+// MFMA (the V^T fragments of the attention kernel: 12 LDS instructions per 8 MFMAs in all)
+template <int NACC, int FILL, int MFMA = 1, int LDSOP = 0>
 __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ src, float* __restrict__ out,
                                                  unsigned long long* __restrict__ stamps, int iters) {
   const int tid = threadIdx.x, gid = blockIdx.x * 256 + tid;
@@ -37,11 +40,31 @@ __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ sr
   unsigned pk = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) x[r] = -0.01f * (float)((tid + r) & 63);
+  __shared__ __attribute__((aligned(16))) char lds[32768];
+  typedef __attribute__((ext_vector_type(4))) short s4;
+  s4 trsink = {0, 0, 0, 0};
+  if constexpr (LDSOP) {
+    for (int i = tid; i < 2048; i += 256) reinterpret_cast<f16x8_t*>(lds)[i] = a[i & 3];
+    __syncthreads();
+  }
+  const char* lbase = lds + (tid & 63) * 16 + (tid >> 6) * 4096;     // lane-linear 16-byte reads: conflict-free
+  f16x8_t la[2];
+  if constexpr (LDSOP) { la[0] = *reinterpret_cast<const f16x8_t*>(lbase); la[1] = la[0]; }
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      if constexpr (MFMA) acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m & 3], b[m & 3], acc[m % NACC], 0, 0, 0);
+      if constexpr (LDSOP) {
+        la[(m + 1) & 1] = *reinterpret_cast<const f16x8_t*>(lbase + 1024 * ((m + 1) & 3));      // operand of the NEXT MFMA
+        if constexpr (LDSOP == 2) {
+          if (m & 1) {
+            const s4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(lbase + 2048));
+            const s4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(lbase + 3072));
+            trsink ^= t0 ^ t1;
+          }
+        }
+        if constexpr (MFMA) acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(la[m & 1], b[m & 3], acc[m % NACC], 0, 0, 0);
+      } else if constexpr (MFMA) acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m & 3], b[m & 3], acc[m % NACC], 0, 0, 0);
       // exact instruction mixes in asm (nothing for the compiler to hoist, fuse or chain): the adds and the conversion
       // consume the exps of the PREVIOUS gap (no VALU result is used right after it is produced)
       float& ea0 = (m & 1) ? eB0 : eA0; float& ea1 = (m & 1) ? eB1 : eA1;       // written in this gap
@@ -64,7 +87,7 @@ __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ sr
     }
   }
   const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  float sum = s0 + s1 + (float)(pk & 1) + eA0 + eA1 + eB0 + eB1;
+  float sum = s0 + s1 + (float)(pk & 1) + eA0 + eA1 + eB0 + eB1 + (float)trsink[0];
 #pragma unroll
   for (int n = 0; n < NACC; ++n)
 #pragma unroll
@@ -77,7 +100,7 @@ __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ sr
   }
 }
 
-template <int NACC, int FILL, int MFMA = 1> void run(const char* name, int waves_per_simd, const _Float16* src, float* out, unsigned long long* st) {
+template <int NACC, int FILL, int MFMA = 1, int LDSOP = 0> void run(const char* name, int waves_per_simd, const _Float16* src, float* out, unsigned long long* st) {
   hipDeviceProp_t p;
   (void)hipGetDeviceProperties(&p, 0);
   const int cus = p.multiProcessorCount;
@@ -87,7 +110,7 @@ template <int NACC, int FILL, int MFMA = 1> void run(const char* name, int waves
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {               // repeat: the clock settles under sustained load
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((mfma_loop<NACC, FILL, MFMA>), dim3(blocks), dim3(256), 0, 0, src, out, st, iters);
+    hipLaunchKernelGGL((mfma_loop<NACC, FILL, MFMA, LDSOP>), dim3(blocks), dim3(256), 0, 0, src, out, st, iters);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
   }
@@ -115,10 +138,13 @@ int main() {
   (void)hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   (void)hipMalloc(&out, 256 * 8 * 256 * 4);
   (void)hipMalloc(&st, 256 * 8 * 4 * 16);
-  for (int w = 1; w <= 3; ++w) {
+  for (int w = 1; w <= 2; ++w) {
     run<4, 0>("bare MFMA, 4 independent accumulators", w, src, out, st);
     run<1, 0>("bare MFMA, one accumulator chain", w, src, out, st);
     run<4, 1>("MFMA + 2 v_exp + 2 v_add + 1 v_cvt_pk", w, src, out, st);
+    run<4, 0, 1, 1>("bare MFMA, A operand by ds_read_b128", w, src, out, st);
+    run<4, 1, 1, 1>("MFMA + softmax mix, A operand by ds_read_b128", w, src, out, st);
+    run<4, 1, 1, 2>("MFMA + softmax mix, 12 LDS reads per 8 MFMAs", w, src, out, st);
     run<4, 2>("MFMA + 2 v_exp", w, src, out, st);
     run<4, 3>("MFMA + 1 v_exp", w, src, out, st);
     run<4, 4>("MFMA + 4 v_add + 1 v_cvt_pk", w, src, out, st);
