@@ -91,7 +91,11 @@ __device__ __forceinline__ s16x8_t load_vt(const char* a0, const char* a1, int i
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int OFF> __device__ __forceinline__ void load_v1(const LdsBases& b, VFrag& f, int i) {
+template <int OFF, int ABL = 0> __device__ __forceinline__ void load_v1(const LdsBases& b, VFrag& f, int i) {
+  if constexpr (ABL == 6) {   // timing only: what a V^T image readable with ONE ds_read_b128 per fragment would cost
+    f.v[i] = *reinterpret_cast<const s16x8_t*>((i == 0 ? b.ka0 : i == 1 ? b.ka1 : i == 2 ? b.ka2 : b.ka3) + OFF);
+    return;
+  }
   f.v[i] = load_vt(b.va0, b.va1, OFF + 2048 * (i >> 1) + 512 * (i & 1));
 }
 template <int OFF> __device__ __forceinline__ void load_v(const LdsBases& b, VFrag& f) {
@@ -260,10 +264,10 @@ __device__ __forceinline__ void attn_slot(const LdsBases& b, const QFrag (&q)[RB
       if (g < 2) {
         if constexpr (PF_K) { load_k1<NK_OFF>(b, kn, 2 * g); load_k1<NK_OFF>(b, kn, 2 * g + 1); }
       } else if (g < 4) {
-        load_v1<NV_OFF>(b, vn, g - 2);
+        load_v1<NV_OFF, ABL>(b, vn, g - 2);
       } else if (RB == 2 ? (g == 4 || g == 5) : (g == 4)) {
-        if constexpr (RB == 2) load_v1<NV_OFF>(b, vn, g - 2);
-        else { load_v1<NV_OFF>(b, vn, 2); load_v1<NV_OFF>(b, vn, 3); }
+        if constexpr (RB == 2) load_v1<NV_OFF, ABL>(b, vn, g - 2);
+        else { load_v1<NV_OFF, ABL>(b, vn, 2); load_v1<NV_OFF, ABL>(b, vn, 3); }
       }
     }
     {
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(256, RB == 2 ? 1 : 2) void attn_pipe_kernel(const u
   int t = 0;
   unsigned long long stamp_c0 = 0, stamp_r0 = 0;
   if constexpr (ABL == 5) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
-  if constexpr (ABL == 0 || ABL == 5) {
+  if constexpr (ABL == 0 || ABL == 5 || ABL == 6) {
     COLD_TILE()                                   // tile 0 (published by the prologue barrier)
     while (t + 3 <= nt - 1) {                     // steady state: t % 3 == 1 here
       PIPE_TILE_BARRIER(0) PIPE_TILE(1)
@@ -729,6 +733,10 @@ int vittf_attention_pipe(const void* qkv, void* out, int32_t batch, int32_t toke
   if (rb == 1) {
     if (dtype == VITTF_BF16) PIPE_LAUNCH(VITTF_BF16, 0, 1);
     else if (abl == 5) PIPE_LAUNCH(VITTF_FP16, 5, 1);
+    else if (abl == 6) PIPE_LAUNCH(VITTF_FP16, 6, 1);
+    else if (abl == 4) PIPE_LAUNCH(VITTF_FP16, 4, 1);
+    else if (abl == 1) PIPE_LAUNCH(VITTF_FP16, 1, 1);
+    else if (abl == 2) PIPE_LAUNCH(VITTF_FP16, 2, 1);
     else PIPE_LAUNCH(VITTF_FP16, 0, 1);
   } else {
     if (dtype == VITTF_BF16) PIPE_LAUNCH(VITTF_BF16, 0, 2);
