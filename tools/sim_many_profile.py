@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Where the time of a 5 x 1024-query similarity call goes (BASELINE configs[4]): whole call (maps to the host / left on the
+device) against host-side pieces.  tools only."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import vit_tf_amd as vt
+
+dev = torch.device('cuda', 0)
+g = torch.Generator().manual_seed(0)
+feat = torch.randn(384, 64, 64, 64, generator=g).half().to(dev)
+ann = {f'c{i}': torch.randint(0, 256, (1024, 3), generator=g) for i in range(5)}
+vol = np.zeros((256, 256, 256), np.float32)
+
+def t(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+print(f'maps to the host      : {t(lambda: vt.compute_similarities(vol, feat, ann)):.2f} ms')
+print(f'maps left on the GPU  : {t(lambda: vt.compute_similarities(vol, feat, ann, keep_on_device=True)):.2f} ms')
+os.environ['VITTF_SIM_MFMA'] = '0'
+print(f'VALU kernel (MFMA off): {t(lambda: vt.compute_similarities(vol, feat, ann, keep_on_device=True), reps=3):.2f} ms')

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void sim_mfma_prep(const float* __restrict__ q
   *reinterpret_cast<uint4*>(dst + SM_PART) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
-__device__ __forceinline__ float sm_thresh_pow(float s) { return s >= 0.25f ? s * s * sqrtf(s) : 0.f; }
+__device__ __forceinline__ float sm_thresh_pow(float s) { return s >= 0.25f ? s * s * sqrt_cr_normal(s) : 0.f; }   // (vittf_common.h: same bits as sqrtf, a third of its instructions)
 
 __global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned short* __restrict__ feat, int64_t nvox,
                                                               const char* __restrict__ qimg,

@@ -152,19 +152,6 @@ __global__ __launch_bounds__(256) void transpose_queries(const float* __restrict
   qf_t[e] = a < n_ann ? qf[(int64_t)(a0 + a) * f + ff] : 0.f;
 }
 
-// sqrtf for NORMAL positive x, correctly rounded: v_sqrt_f32 (1 ulp) + the library's own correction step (try the two
-// neighbours, keep the one whose square brackets x) without its scaling of denormal inputs -- the same bits as sqrtf for
-// every x the threshold lets through, a third of the instructions and none of the per-element condition masks that made
-// 64 inlined sqrtf calls spill 140-190 registers at this kernel's 128-VGPR budget.
-__device__ __forceinline__ float sqrt_cr_normal(float x) {
-  float y = __builtin_amdgcn_sqrtf(x);
-  const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
-  const float rm = fmaf(-ym, y, x), rp = fmaf(-yp, y, x);
-  y = rm <= 0.f ? ym : y;
-  y = rp > 0.f ? yp : y;
-  return y;
-}
-
 __device__ __forceinline__ float thresh_pow(float s) {
   // where(s >= 0.25, s, 0) ** 2.5   (predict_ntf.py:71)
   return s >= 0.25f ? s * s * sqrt_cr_normal(s) : 0.f;

@@ -98,6 +98,19 @@ __device__ __forceinline__ float gelu_poly(float x) {
   return fmaf(-fabsf(x), e, fmaxf(x, 0.f));                    // max(x, 0) - |x| 0.5 erfc(|x| / sqrt 2): both signs, 9 VALU
 }
 
+// sqrtf for NORMAL positive x, correctly rounded: v_sqrt_f32 (1 ulp) + the library's own correction step (try the two
+// neighbours, keep the one whose square brackets x) without its scaling of denormal inputs -- the same bits as sqrtf for
+// every x the threshold lets through, a third of the instructions and none of the per-element condition masks that made
+// 64 inlined sqrtf calls spill 140-190 registers at this kernel's 128-VGPR budget.
+__device__ __forceinline__ float sqrt_cr_normal(float x) {
+  float y = __builtin_amdgcn_sqrtf(x);
+  const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+  const float rm = fmaf(-ym, y, x), rp = fmaf(-yp, y, x);
+  y = rm <= 0.f ? ym : y;
+  y = rp > 0.f ? yp : y;
+  return y;
+}
+
 // ---- LDS-DMA hidden from hipcc -------------------------------------------------------------------------------
 // One piece: 64 lanes x 16 B -> 1 KB at LDS byte address lds_addr (lane-linear), fetched through a buffer descriptor
 // (bytes past num_records read as zeros).  hipcc orders every later ds_read / ds_write against an outstanding
