@@ -42,7 +42,7 @@ for s in "$@"; do
     prof8)    cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               SETTLE_S=0.05 step prof8 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof8 -- python tools/bench_kernels.py attn8 ;;
     benchbatch) for eb in 64 128 256 512; do VITTF_BENCH_OVERLAP=0 step benchbatch_$eb 600 python bench.py --engine-batch $eb --cpu-slices 0 --steps 2; done ;;
-    benchenv) for e in VITTF_ROWS_WM=1 VITTF_ROWS_WM=2; do env $e VITTF_BENCH_OVERLAP=0 bash -c 'true'; export $e; VITTF_BENCH_OVERLAP=0 step benchenv_${e}_$RANDOM 600 python bench.py --cpu-slices 0 --steps 2; unset ${e%%=*}; done ;;
+    benchenv) for e in ${BENCHENV:-VITTF_ROWS_WM=1 VITTF_ROWS_WM=2}; do export $e; VITTF_BENCH_OVERLAP=0 step benchenv_${e}_$RANDOM 600 python bench.py --cpu-slices 0 --steps 2; unset ${e%%=*}; done ;;
     bench512) step bench512 900 python bench.py ;;
     prof512)  cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               export VITTF_BENCH_OVERLAP=0
