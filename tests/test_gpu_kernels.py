@@ -69,7 +69,8 @@ def test_gemm_bias_and_gelu(gpu, dt, rows, n, k):
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-@pytest.mark.parametrize('rows,n,k', [(3, 128, 64), (515, 384, 384), (200, 384, 1536), (33000, 384, 384), (1030, 384, 1536), (256, 384, 64)])
+@pytest.mark.parametrize('rows,n,k', [(3, 128, 64), (515, 384, 384), (200, 384, 1536), (33000, 384, 384), (1030, 384, 1536), (256, 384, 64),
+                                       (515, 768, 768), (200, 768, 3072), (33000, 768, 768), (129, 768, 64)])
 def test_gemm_residual(gpu, dt, rows, n, k):
     lib = _lib.load()
     a, w, bias, ref = _gemm_inputs(rows, n, k, dt, rows * 3 + n)
@@ -699,8 +700,18 @@ def rows_wm(request, monkeypatch):
 def test_gemm_residual_ln(gpu, dt, rows, k, rows_wm):
     """x += a . w^T + bias and h = LayerNorm(x) in one call (whole-row GEMM with the LayerNorm in its epilogue + the tiled /
     LayerNorm kernels for the rows beyond the last full 256-row tile) against fp64 and against the separate kernels."""
+    _residual_ln_case(gpu, dt, rows, 384, k)
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows,k', [(128, 768), (1030, 3072), (33000, 768), (4097 * 2, 3072), (100, 768), (257, 64)])
+def test_gemm_residual_ln_768_columns(gpu, dt, rows, k):
+    """The same with 768 output columns (ViT-B/8 proj and fc2: 8 waves side by side, 128-row workgroups)."""
+    _residual_ln_case(gpu, dt, rows, 768, k)
+
+
+def _residual_ln_case(gpu, dt, rows, n, k):
     lib = _lib.load()
-    n = 384
     a, w, bias, ref = _gemm_inputs(rows, n, k, dt, rows + k)
     g = gen(rows)
     x0 = torch.randn(rows + 2, n, generator=g) * 3.0

@@ -132,10 +132,10 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   // 16-bit rows), which costs more than the LayerNorm launches: 1690 against 1720 slices/s on the 256^3 workload.
   static const bool ln_fused_env = [] { const char* e = getenv("VITTF_LN_FUSED"); return e && atoi(e) != 0; }();
   const bool ln_fused = ln_fused_env && d == 384 && !(w->fc2_w_perm);
-  // ViT-S default: every LayerNorm but the first rides on the epilogue of the residual GEMM in front of it
+  // Default (D = 384 / 768): every LayerNorm but the first rides on the epilogue of the residual GEMM in front of it
   // (vittf_gemm_residual_ln: proj -> norm2, fc2 -> the next block's norm1); VITTF_RESIDUAL_LN=0 keeps them separate.
   static const bool res_ln_env = [] { const char* e = getenv("VITTF_RESIDUAL_LN"); return !e || atoi(e) != 0; }();
-  const bool res_ln = res_ln_env && d == 384 && !ln_fused && !(w->fc2_w_perm);
+  const bool res_ln = res_ln_env && (d == 384 || d == 768) && !ln_fused && !(w->fc2_w_perm);
   for (int l = 0; l < L; ++l) {
     const char* qkv_w = (const char*)w->qkv_w + (size_t)l * 3 * d * d * esz;
     if (res_ln ? l == 0 : (!ln_fused || l == L - 1)) {

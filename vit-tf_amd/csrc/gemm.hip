@@ -292,10 +292,10 @@ extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void*
     const int rc = vittf_gemm_ws(a, w, bias, out, rows, n, k, epilogue, dtype, st);
     if (rc != 1) return rc;
   }
-  // residual epilogue with 384 output columns (ViT-S proj / fc2): whole-row kernel for the full 256-row tiles, the tiled
-  // kernel below for the remaining rows (VITTF_GEMM_ROWS=0: tiled kernel only)
+  // residual epilogue with 384 / 768 output columns (ViT-S / ViT-B proj and fc2): whole-row kernel (VITTF_GEMM_ROWS=0:
+  // tiled kernel only)
   static const bool use_rows = [] { const char* e = getenv("VITTF_GEMM_ROWS"); return !e || atoi(e) != 0; }();
-  if (use_rows && epilogue == VITTF_EPI_BIAS_RESIDUAL && n == 384) {
+  if (use_rows && epilogue == VITTF_EPI_BIAS_RESIDUAL && (n == 384 || n == 768)) {
     const int rc = vittf_gemm_rows(a, w, bias, (float*)out, rows, n, k, dtype, nullptr, nullptr, 0.f, nullptr, st);
     if (rc != 1) return rc;
   }
@@ -315,7 +315,7 @@ extern "C" int vittf_gemm_residual_ln(const void* a, const void* w, const float*
   if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   static const bool use_rows = [] { const char* e = getenv("VITTF_GEMM_ROWS"); return !e || atoi(e) != 0; }();
-  if (use_rows && n == 384) {
+  if (use_rows && (n == 384 || n == 768)) {
     const int rc = vittf_gemm_rows(a, w, bias, x, rows, n, k, dtype, ln_g, ln_b, ln_eps, h, st);
     if (rc != 1) return rc;
   }

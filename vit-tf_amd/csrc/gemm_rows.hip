@@ -1,6 +1,7 @@
-// Whole-row MFMA GEMM for the residual linears of ViT-S (attn.proj, mlp.fc2):
-//     x[rows][384] (fp32) += A[rows][K] . W[384][K]^T + bias          (K = 384 or 1536)
-// and, optionally in the same pass, the next LayerNorm:  h[rows][384] (16 bit) = LayerNorm(x_new; g, b).
+// Whole-row MFMA GEMM for the residual linears (attn.proj, mlp.fc2) of ViT-S (D = 384) and ViT-B (D = 768):
+//     x[rows][D] (fp32) += A[rows][K] . W[D][K]^T + bias          (K = D or 4 D)
+// and, optionally in the same pass, the next LayerNorm:  h[rows][D] (16 bit) = LayerNorm(x_new; g, b).
+// (The text below describes D = 384; D = 768 is the same kernel with 8 waves side by side on 128 rows: RowsCfg.)
 //
 // Why next to gemm.hip: a 128 x 128 tile moves 32 KB of operands from L2 into LDS per 64-wide K step, 2.36 GB per fc2
 // launch, and its run time follows L2->LDS bytes / ~17 TB/s + HBM bytes / ~5 TB/s.  Here a workgroup owns whole rows:
@@ -31,23 +32,32 @@
 
 namespace {
 
-constexpr int RN = 384, RBK = 32;
-constexpr int RW_BYTES = RN * RBK * 2;            // 24 KB
-constexpr int RCS = RN * 4 + 16;                  // fp32 staging row stride
+constexpr int RBK = 32;
 
-// WM = row halves per workgroup: 2 -> 256 rows, 8 waves, 3-deep ring, one workgroup per CU;
-//                                1 -> 128 rows, 4 waves, 2-deep ring, two workgroups per CU (the epilogue of one
-//                                     overlaps the K loop of the other; the weight image is staged twice as often)
-template <int WM>
+// RN = output columns = the embedding width: 384 (ViT-S) or 768 (ViT-B); a wave owns 96 of them, so NW = 4 or 8 waves
+// side by side.
+// WM = row halves per workgroup: 2 -> 256 rows, 8 waves, 3-deep ring, one workgroup per CU (RN = 384 only);
+//                                1 -> 128 rows, NW waves, 2-deep ring; RN = 384: two workgroups per CU (the epilogue of
+//                                     one overlaps the K loop of the other; the weight image is staged twice as often),
+//                                     RN = 768: 8 waves, 56 KB stages, one workgroup per CU
+template <int WM, int RN>
 struct RowsCfg {
-  static constexpr int BM = 128 * WM, THREADS = 256 * WM;
+  static constexpr int NW = RN / 96;
+  static constexpr int BM = 128 * WM, THREADS = 64 * WM * NW;
   static constexpr int A_BYTES = BM * RBK * 2;                // 16 / 8 KB
-  static constexpr int STAGE = A_BYTES + RW_BYTES;            // 40 / 32 KB
+  static constexpr int RW_BYTES = RN * RBK * 2;               // 24 / 48 KB
+  static constexpr int STAGE = A_BYTES + RW_BYTES;            // 40 / 32 / 56 KB
   static constexpr int STAGES = WM == 2 ? 3 : 2;
-  static constexpr int LDS = STAGES * STAGE;                  // 122,880 / 65,536 B
+  static constexpr int LDS = STAGES * STAGE;                  // 122,880 / 65,536 / 114,688 B
+  static constexpr int RCS = RN * 4 + 16;                     // fp32 staging row stride
   static constexpr int BIAS_OFF = 32 * WM * RCS;              // bias / gamma / beta behind the staging tile
-  static constexpr int W_PIECES = RW_BYTES / (THREADS * 16);  // 3 / 6 per thread and stage (+ 2 of the activation image)
+  static constexpr int A_PIECES = A_BYTES / (THREADS * 16);   // 2 / 2 / 1 LDS-DMA pieces per thread and stage
+  static constexpr int W_PIECES = RW_BYTES / (THREADS * 16);  // 6 / 3 / 6
+  static constexpr int LPR = RN / 24;                         // epilogue: lanes per row (24 values each): 16 / 32
+  static_assert(RN == 384 || (RN == 768 && WM == 1), "shapes: 384 columns (128 / 256 rows) or 768 columns (128 rows)");
+  static_assert(A_PIECES * THREADS * 16 == A_BYTES && W_PIECES * THREADS * 16 == RW_BYTES && (W_PIECES == 3 || W_PIECES == 6), "pieces");
   static_assert(BIAS_OFF + 3 * RN * 4 <= LDS, "staging tile + bias / gamma / beta must fit in the ring");
+  static_assert(32 * WM * LPR == 2 * THREADS, "two epilogue passes per 32-row round");
 };
 
 #define ROWS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -55,23 +65,24 @@ struct RowsCfg {
 // byte offset of 16-byte k-chunk kc (0..3) of row r inside a [R][32] operand image
 __device__ __forceinline__ int img_off(int r, int kc) { return tile_off(r >> 1, ((r & 1) << 2) | kc); }
 
-template <int DT, bool LN, int WM>
-__global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_rows_kernel(
+template <int DT, bool LN, int WM, int RN>
+__global__ __launch_bounds__((RowsCfg<WM, RN>::THREADS)) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_rows_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ X, int64_t rows, int k, const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
     unsigned short* __restrict__ H) {
-  using C = RowsCfg<WM>;
+  using C = RowsCfg<WM, RN>;
   constexpr int RBM = C::BM, RTHREADS = C::THREADS, RA_BYTES = C::A_BYTES, RSTAGE = C::STAGE, RSTAGES = C::STAGES;
-  constexpr int RBIAS_OFF = C::BIAS_OFF;
+  constexpr int RBIAS_OFF = C::BIAS_OFF, RCS = C::RCS, NW = C::NW, A_PIECES = C::A_PIECES, W_PIECES = C::W_PIECES, LPR = C::LPR;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int wm = WM == 2 ? wave >> 2 : 0, wn = wave & 3;
+  const int wm = WM == 2 ? wave / NW : 0, wn = wave % NW;
   const int64_t m0 = (int64_t)blockIdx.x * RBM;
 
-  // ---- LDS-DMA pieces per thread and stage: 2 of the activation image, 3 / 6 of the weight image (pieces 3..5 of the
-  //      128-row variant are pieces 0..2 shifted by 192 weight rows: same lane offset, + 192 k 2 in the scalar offset)
+  // ---- LDS-DMA pieces per thread and stage: 2 / 1 of the activation image (voff[0..1]), 3 / 6 of the weight image
+  //      (voff[2..4]; pieces 3..5 are pieces 0..2 shifted by 3 THREADS / 4 weight rows: same lane offset, the shift in the
+  //      scalar offset)
   int voff[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
@@ -88,17 +99,17 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
   const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(smem);
   const unsigned dma_wave = ring_lds + wave * 1024;
   constexpr int PIECE = RTHREADS * 16;             // LDS bytes one piece of all threads covers (8 / 4 KB)
-  const int w_half = 192 * k * 2;
+  const int w_half = (3 * RTHREADS / 4) * k * 2;
 #define ROWS_STAGE(T, BUF)                                                                      \
   {                                                                                             \
     const unsigned dst_ = dma_wave + (BUF) * RSTAGE;                                            \
     const int so_ = (T) * (RBK * 2);                                                            \
     lds_dma16(rsrc_a, dst_, voff[0], so_);                                                      \
-    lds_dma16(rsrc_a, dst_ + PIECE, voff[1], so_);                                              \
+    if (A_PIECES == 2) lds_dma16(rsrc_a, dst_ + PIECE, voff[1], so_);                           \
     lds_dma16(rsrc_w, dst_ + RA_BYTES, voff[2], so_);                                           \
     lds_dma16(rsrc_w, dst_ + RA_BYTES + PIECE, voff[3], so_);                                   \
     lds_dma16(rsrc_w, dst_ + RA_BYTES + 2 * PIECE, voff[4], so_);                               \
-    if (WM == 1) {                                                                              \
+    if (W_PIECES == 6) {                                                                        \
       lds_dma16(rsrc_w, dst_ + RA_BYTES + 3 * PIECE, voff[2], so_ + w_half);                    \
       lds_dma16(rsrc_w, dst_ + RA_BYTES + 4 * PIECE, voff[3], so_ + w_half);                    \
       lds_dma16(rsrc_w, dst_ + RA_BYTES + 5 * PIECE, voff[4], so_ + w_half);                    \
@@ -167,14 +178,14 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
   // so a load waited for behind earlier stores would also wait for those stores.
   int tid_e = tid;
   asm volatile("" : "+v"(tid_e));   // opaque: keeps the epilogue's lane-derived addresses out of the main loop's registers
-  const int row_p = tid_e >> 4, seg = tid_e & 15;
+  const int row_p = tid_e / LPR, seg = tid_e % LPR;
   float4 xn[6];
 #define ROWS_LOADX(MB, P)                                                                       \
   {                                                                                             \
-    const int sr_ = (P) * (RTHREADS / 16) + row_p;                                              \
+    const int sr_ = (P) * (RTHREADS / LPR) + row_p;                                              \
     const int rl_ = (sr_ >> 5) * 128 + 32 * (MB) + (sr_ & 31);                                  \
     const float* xr_ = X + (m0 + (rl_ < rows_here ? rl_ : rows_here - 1)) * RN + seg * 4;       \
-    _Pragma("unroll") for (int j = 0; j < 6; ++j) xn[j] = *reinterpret_cast<const float4*>(xr_ + 64 * j); \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j) xn[j] = *reinterpret_cast<const float4*>(xr_ + 4 * LPR * j); \
   }
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
     ROWS_BARRIER();
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const int srow = p * (RTHREADS / 16) + row_p;                 // row of the staging tile
+      const int srow = p * (RTHREADS / LPR) + row_p;                 // row of the staging tile
       const int rl = (srow >> 5) * 128 + 32 * mb + (srow & 31);     // row of the workgroup's tile
       const int64_t gm = m0 + rl;
       const bool live = rl < rows_here;
@@ -213,15 +224,16 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const float4 d = *reinterpret_cast<const float4*>(sr + 256 * j);
+        const float4 d = *reinterpret_cast<const float4*>(sr + 16 * LPR * j);
         x[j].x += d.x; x[j].y += d.y; x[j].z += d.z; x[j].w += d.w;
-        if (live) *reinterpret_cast<float4*>(xw + 64 * j) = x[j];
+        if (live) *reinterpret_cast<float4*>(xw + 4 * LPR * j) = x[j];
         s += (x[j].x + x[j].y) + (x[j].z + x[j].w);
       }
       __builtin_amdgcn_sched_barrier(0);   // (keeps the LayerNorm's LDS reads from being hoisted into the loop above: spills)
       if constexpr (LN) {
         // the row's 384 new values sit in these 16 lanes (24 each): statistics by 4 shuffles, arithmetic of layernorm.hip
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        if (LPR == 32) s += __shfl_xor(s, 16);
         const float mean = s / (float)RN;
         float q = 0.f;
 #pragma unroll
@@ -230,17 +242,18 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
           q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
         }
         q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+        if (LPR == 32) q += __shfl_xor(q, 16);
         const float rstd = 1.0f / sqrtf(q / (float)RN + ln_eps);
         unsigned short* hr = H + gm * RN + seg * 4;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-          const float4 gg = *reinterpret_cast<const float4*>(sbias + RN + seg * 4 + 64 * j);
-          const float4 bb = *reinterpret_cast<const float4*>(sbias + 2 * RN + seg * 4 + 64 * j);
+          const float4 gg = *reinterpret_cast<const float4*>(sbias + RN + seg * 4 + 4 * LPR * j);
+          const float4 bb = *reinterpret_cast<const float4*>(sbias + 2 * RN + seg * 4 + 4 * LPR * j);
           uint2 pk;
           pk.x = pack2_h16<DT>(x[j].x * rstd * gg.x + bb.x, x[j].y * rstd * gg.y + bb.y);
           pk.y = pack2_h16<DT>(x[j].z * rstd * gg.z + bb.z, x[j].w * rstd * gg.w + bb.w);
-          if (live) *reinterpret_cast<uint2*>(hr + 64 * j) = pk;
+          if (live) *reinterpret_cast<uint2*>(hr + 4 * LPR * j) = pk;
         }
       }
     }
@@ -253,24 +266,24 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
 // 1 = shape not covered
 int vittf_gemm_rows(const void* a, const void* w, const float* bias, float* x, int64_t rows, int32_t n, int32_t k,
                     int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h, hipStream_t st) {
-  if (n != RN || k % RBK != 0 || k < 2 * RBK || rows <= 0) return 1;
+  if ((n != 384 && n != 768) || k % RBK != 0 || k < 2 * RBK || rows <= 0) return 1;
   if ((int64_t)256 * k * 2 > 0x7fffffff || rows / 128 + 1 > 0x7fffffff) return 1;
   if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
   // Workgroup shape by K (never by the row count: results must not depend on how the rows are batched): the 256-row
   // shape for the long-K linear (fc2: 239 against 254 ms per 3072 slices), the 128-row one for proj (123 against 127).
   // VITTF_ROWS_WM=1|2 forces one shape (read per call: the tests switch it).
   const char* wm_env = getenv("VITTF_ROWS_WM");
-  const int wm = wm_env ? (atoi(wm_env) == 2 ? 2 : 1) : (k >= 1024 ? 2 : 1);
+  const int wm = n == 768 ? 1 : (wm_env ? (atoi(wm_env) == 2 ? 2 : 1) : (k >= 1024 ? 2 : 1));
   const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Wp = (const unsigned short*)w;
   const bool ln = ln_g && ln_b && h;
   const int bm = 128 * wm;
-  const dim3 grid((unsigned)((rows + bm - 1) / bm)), block(256 * wm);
-#define ROWS_LAUNCH(DT, LN, WM)                                                                                     \
-  hipLaunchKernelGGL((gemm_rows_kernel<DT, LN, WM>), grid, block, 0, st, A, Wp, bias, x, rows, k, ln_g, ln_b, ln_eps, \
+  const dim3 grid((unsigned)((rows + bm - 1) / bm)), block(n == 768 ? 512 : 256 * wm);
+#define ROWS_LAUNCH(DT, LN, WM, RNV)                                                                                     \
+  hipLaunchKernelGGL((gemm_rows_kernel<DT, LN, WM, RNV>), grid, block, 0, st, A, Wp, bias, x, rows, k, ln_g, ln_b, ln_eps, \
                      (unsigned short*)h)
 #define ROWS_LAUNCH_WM(DT, LN) \
-  { if (wm == 2) ROWS_LAUNCH(DT, LN, 2); else ROWS_LAUNCH(DT, LN, 1); }
+  { if (n == 768) ROWS_LAUNCH(DT, LN, 1, 768); else if (wm == 2) ROWS_LAUNCH(DT, LN, 2, 384); else ROWS_LAUNCH(DT, LN, 1, 384); }
   if (dtype == VITTF_BF16) {
     if (ln) ROWS_LAUNCH_WM(VITTF_BF16, true) else ROWS_LAUNCH_WM(VITTF_BF16, false)
   } else {
