@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ sr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
   float x[16], s0 = 0.f, s1 = 0.f, eA0 = 0.f, eA1 = 0.f, eB0 = 0.f, eB1 = 0.f;
-  unsigned pk = 0;
+  unsigned pk = 0, pk2 = 0, pkprev = 0xb800b400u;
+  __attribute__((ext_vector_type(4))) float lsum0 = {0.f, 0.f, 0.f, 0.f}, lsum1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < 16; ++r) x[r] = -0.01f * (float)((tid + r) & 63);
   __shared__ __attribute__((aligned(16))) char lds[32768];
@@ -79,6 +80,25 @@ __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ sr
       } else if constexpr (FILL == 4) { // five plain VALU
         asm volatile("v_add_f32 %0, %5, %6\n\tv_add_f32 %1, %5, %6\n\tv_add_f32 %2, %2, %7\n\tv_add_f32 %3, %3, %8\n\tv_cvt_pk_f16_f32 %4, %7, %8"
                      : "=&v"(ea0), "=&v"(ea1), "+v"(s0), "+v"(s1), "=&v"(pk) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1));
+      } else if constexpr (FILL == 6) { // f16 exponentials on packed halves: 1 v_cvt_pk + 2 v_exp_f16 (lo, hi by op_sel) per MFMA
+        asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_exp_f16 %1, %4\n\tv_exp_f16_sdwa %1, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"
+                     : "=&v"(pk), "+v"(pk2) : "v"(x[0]), "v"(x[1]), "v"(pkprev));
+        pkprev = pk;
+      } else if constexpr (FILL == 8) { // the mix with its row sums on the matrix pipe: 2 v_exp + 1 v_cvt_pk per MFMA, and per
+                                        // 2 MFMAs one v_mfma_f32_4x4x4_16B_f16 with A = ones (sums the 4 packed halves a lane holds)
+        asm volatile("v_exp_f32 %0, %3\n\tv_exp_f32 %1, %4\n\tv_cvt_pk_f16_f32 %2, %5, %6"
+                     : "=&v"(ea0), "=&v"(ea1), "=&v"(pk) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1));
+        if (m & 1) {
+          typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+          typedef __attribute__((ext_vector_type(4))) float f4;
+          union { unsigned u[2]; h4 v; } pb; pb.u[0] = pk; pb.u[1] = pkprev;
+          const h4 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+          f4& la4 = (m & 2) ? lsum1 : lsum0;
+          la4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, pb.v, la4, 0, 0, 0);
+        }
+        pkprev = pk;
+      } else if constexpr (FILL == 7) { // two v_exp_f16 only
+        asm volatile("v_exp_f16 %0, %1\n\tv_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(pk2) : "v"(pkprev));
       } else if constexpr (FILL == 5) { // three plain VALU (the mix without its exps)
         asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_cvt_pk_f16_f32 %2, %3, %4"
                      : "+v"(s0), "+v"(s1), "=&v"(pk) : "v"(eb0), "v"(eb1));
@@ -87,7 +107,7 @@ __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ sr
     }
   }
   const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  float sum = s0 + s1 + (float)(pk & 1) + eA0 + eA1 + eB0 + eB1 + (float)trsink[0];
+  float sum = s0 + s1 + (float)(pk & 1) + (float)(pk2 & 3) + lsum0[0] + lsum1[1] + eA0 + eA1 + eB0 + eB1 + (float)trsink[0];
 #pragma unroll
   for (int n = 0; n < NACC; ++n)
 #pragma unroll
@@ -149,6 +169,11 @@ int main() {
     run<4, 3>("MFMA + 1 v_exp", w, src, out, st);
     run<4, 4>("MFMA + 4 v_add + 1 v_cvt_pk", w, src, out, st);
     run<4, 5>("MFMA + 2 v_add + 1 v_cvt_pk", w, src, out, st);
+    run<4, 8>("MFMA + 2 v_exp + 1 v_cvt_pk + 1/2 mfma_4x4x4 (row sums)", w, src, out, st);
+    run<4, 6>("MFMA + 1 v_cvt_pk + 2 v_exp_f16", w, src, out, st);
+    run<4, 7>("MFMA + 2 v_exp_f16", w, src, out, st);
+    run<4, 6, 0>("no MFMA: 1 v_cvt_pk + 2 v_exp_f16", w, src, out, st);
+    run<4, 7, 0>("no MFMA: 2 v_exp_f16", w, src, out, st);
     run<4, 1, 0>("no MFMA: 2 v_exp + 2 v_add + 1 v_cvt_pk", w, src, out, st);
     run<4, 2, 0>("no MFMA: 2 v_exp", w, src, out, st);
     run<4, 4, 0>("no MFMA: 4 v_add + 1 v_cvt_pk", w, src, out, st);
