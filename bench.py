@@ -53,6 +53,7 @@ def parse_args():
                     help="vits8 = the BASELINE metric's model; vitb8 = configs[3]'s feature extractor (D = 768), informative")
     ap.add_argument('--attention', type=str, default='16bit', choices=['16bit', 'fp8'],
                     help="fp8 = BASELINE configs[3]'s fp8 MFMA attention path (informative: ~3e-2 on the features, not the contract dtype)")
+    ap.add_argument('--fos', type=int, default=FOS, help='--feature-output-size (64: the metric; 128: the sub/infer_and_merge.sh preset, 1024 x 1024 slices, N = 16385)')
     ap.add_argument('--engine-batch', type=int, default=None, help='slices per engine call (default: extract.DEFAULT_ENGINE_BATCH)')
     ap.add_argument('--cpu-slices', type=int, default=5, help='slices timed for the CPU baseline (0 = skip)')
     return ap.parse_args()
@@ -166,7 +167,7 @@ def cpu_baseline(sd, vol, n_slices, im_sz, arch, feats_cpu, ann, vol_shape):
             if i > 0:
                 times.append(time.perf_counter() - t0)
     out = {'value': round(len(times) / sum(times), 4), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
-           'sample': f'{len(times)} z-slices of the same volume at {im_sz[0]}x{im_sz[1]} (N=4097), batch 1, fp32 torch CPU, '
+           'sample': f'{len(times)} z-slices of the same volume at {im_sz[0]}x{im_sz[1]} (N={(im_sz[0] // 8) * (im_sz[1] // 8) + 1}), batch 1, fp32 torch CPU, '
                      f'after 1 warm-up slice; the oracle runs the K projection of block 12 only, like the GPU path'}
     # similarity: the full 64^3 x 384 feature volume, A = 16, the reference's own formulation
     f32 = feats_cpu.float()
@@ -218,6 +219,8 @@ def main():
     torch.set_num_threads(max(1, host_cores() // max(1, min(world, 8))))   # host-side generation only
     vol, label, desc = make_workload(args.workload, vt)
     desc = desc.replace('ViT-S/8', 'ViT-B/8 (D = 768)') if args.arch == 'vitb8' else desc
+    if args.fos != FOS:
+        desc = desc.replace(f'fos {FOS}', f'fos {args.fos}').replace('512x512 (N=4097)', f'{8 * args.fos}x{8 * args.fos} (N={args.fos * args.fos + 1})') + ' [non-default --fos: not the metric\'s configuration]'
     sd = vt.synthetic_state_dict(args.arch, 0)
     if args.engine_batch is None:
         args.engine_batch = vt.extract.DEFAULT_ENGINE_BATCH
@@ -225,7 +228,7 @@ def main():
     dim, depth, heads, patch = vt.ARCHS[args.arch]
     dvol = vt.DeviceVolume(vol, dev)                     # the input is resident in HBM before the timed region
     ann = query_voxels(label)
-    im_sz, feat_out = vt.sizing(dvol.shape, FOS, 8)
+    im_sz, feat_out = vt.sizing(dvol.shape, args.fos, 8)
     n_tokens = (im_sz[0] // 8) * (im_sz[1] // 8) + 1
     total_slices = sum(dvol.shape)
     my_slices = 0
@@ -236,7 +239,7 @@ def main():
                 vt.extract.window_bounds(w0, dvol.shape[sl], feat_out[sl])[0]
 
     def step():
-        feats = vt.feature_volume(None, model, FOS, 'all', args.engine_batch, dvol=dvol)
+        feats = vt.feature_volume(None, model, args.fos, 'all', args.engine_batch, dvol=dvol)
         sims = vt.compute_similarities(vol, feats, ann, keep_on_device=True)     # maps feed the label kernel directly
         return feats, vt.assign_labels(sims)
 

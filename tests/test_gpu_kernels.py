@@ -462,6 +462,7 @@ def test_similarity_split_kernel_matches_plain_kernel(gpu, monkeypatch):
     ws_bytes = lib.vittf_similarity_workspace_bytes(3, 0, 21)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=gpu)
     maps = {}
+    monkeypatch.setenv('VITTF_SIM_MFMA_MIN', '1000000')       # (21 annotations would take the matrix-core path)
     for split in ('1', '0'):
         monkeypatch.setenv('VITTF_SIM_SPLIT', split)
         out = torch.full((3 * n ** 3 + 1,), 7.0, device=gpu)
@@ -651,6 +652,33 @@ def test_similarity_many_annotations_mfma_path(gpu, normalize):
         d = (got[k].int() - ref[k].int()).abs()
         d = torch.minimum(d, 256 - d)
         assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, (k, int(d.max()), float((d > 0).float().mean()))
+
+
+@pytest.mark.parametrize('grid,counts,min_a', [((7, 9, 11), (70, 3, 33), None),            # 693 voxels: rows not 16-byte aligned -> strided loads
+                                                ((16, 16, 16), (2,) * 40, None),              # 40 classes: tables through device memory
+                                                ((32, 32, 32), (16,), 8), ((24, 20, 18), (5, 1, 9), 8),   # few queries on the matrix cores
+                                                ((64, 8, 8), (1024, 1024), None)])
+def test_similarity_mfma_path_shapes(gpu, monkeypatch, grid, counts, min_a):
+    """The matrix-core similarity path on the shapes around its fast case: voxel counts whose feature rows cannot be
+    fetched as aligned 16-byte chunks, more classes than its by-value class table holds, few queries (threshold lowered
+    with VITTF_SIM_MFMA_MIN), two full 1024-annotation classes -- each against the oracle and against the VALU kernels."""
+    g = gen(sum(grid) + len(counts))
+    feat = torch.nn.functional.normalize(torch.randn(384, *grid, generator=g), dim=0)
+    feat = torch.nn.functional.normalize((feat + 0.7 * feat[:, 2:3, 3:4, 4:5]).half().float(), dim=0).half()
+    shape = tuple(2 * s for s in grid)
+    ann = {f'c{i}': torch.stack([torch.randint(0, s, (n,), generator=g) for s in shape], 1) for i, n in enumerate(counts)}
+    if min_a is not None:
+        monkeypatch.setenv('VITTF_SIM_MFMA_MIN', str(min_a))
+    got = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann)
+    monkeypatch.setenv('VITTF_SIM_MFMA', '0')                                 # (read once per process in the library: see below)
+    monkeypatch.setenv('VITTF_SIM_MFMA_MIN', '1000000')
+    valu = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann)
+    ref = osim.similarity_maps(shape, feat.float(), ann)
+    for k in ann:
+        for name, other in (('oracle', ref[k]), ('VALU kernels', valu[k])):
+            d = (got[k].int() - other.int()).abs()
+            d = torch.minimum(d, 256 - d)
+            assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, (k, name, int(d.max()), float((d > 0).float().mean()))
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Is the HIP-event duration of the 16-query similarity accumulation launch right?  The same launch once per profiler
+scope (what bench.py's roofline_similarity reads) against VITTF_SIM_REPEAT=50 launches inside one scope (duration / 50:
+any per-scope error of the event pair is amortised), and against the wall clock of the repeated launches.
+Run each setting in its own process:  VITTF_SIM_REPEAT=1|50 python tools/sim_event_check.py [fos]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vit_tf_amd as vt  # noqa: E402
+
+
+def main():
+    fos = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    rep = max(1, int(os.environ.get('VITTF_SIM_REPEAT', '1')))
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(0)
+    feat = torch.nn.functional.normalize(torch.randn(384, fos, fos, fos, generator=g), dim=0).half().to(dev)
+    vol = torch.zeros(8 * fos, 8 * fos, 8 * fos, dtype=torch.float16)
+    n_q = int(os.environ.get('QUERIES', '16'))
+    ann = {'q': torch.randint(0, 8 * fos, (n_q, 3), generator=g)}
+    for _ in range(3):
+        vt.compute_similarities(vol, feat, ann, keep_on_device=True)
+    torch.cuda.synchronize()
+    vt._lib.profiler_enable(True, classes=['similarity'])
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        vt.compute_similarities(vol, feat, ann, keep_on_device=True)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / n
+    ms, scopes = vt._lib.profiler_collect()['similarity']
+    vt._lib.profiler_enable(False)
+    nbytes = feat.numel() * 2 + feat[0].numel() * 4
+    per = ms / scopes / rep
+    print(f'fos {fos}, {n_q} queries, VITTF_SIM_MFMA_MIN={os.environ.get("VITTF_SIM_MFMA_MIN", "default")}: {rep} launch(es) per scope: {per * 1e3:.1f} us per launch by events ({nbytes / per / 1e6:.0f} GB/s algorithmic); '
+          f'whole call {wall * 1e3:.3f} ms wall', flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,17 +1,23 @@
-// Per-class similarity maps for MANY annotations on the matrix cores (F = 384).
+// Per-class similarity maps on the matrix cores (F = 384): the interactive few-query case and BASELINE configs[4].
 //
 // Same arithmetic as sim_accumulate (similarity.hip; predict_ntf.py:65, 71-72): for every voxel and class,
-// mean over the class's annotations of where(q . x >= 0.25, q . x, 0) ** 2.5.  The VALU kernel re-reads the whole
-// feature volume for every 16 annotations (A = 5 x 1024, BASELINE configs[4]: 320 passes over 201 MB); here the
-// volume is read ONCE:
+// mean over the class's annotations of where(q . x >= 0.25, q . x, 0) ** 2.5.  The VALU kernel spends 16 FMAs per
+// 2-byte feature element (A = 16: 41 us of VALU issue for a 30 us stream) and re-reads the whole feature volume for
+// every 16 annotations (A = 5 x 1024: 320 passes over 201 MB); here the volume is read ONCE at the speed of the stream:
 //   * workgroup = 8 waves = 256 voxels; a wave keeps the 384 features of its 32 voxels as 24 MFMA B-operands
 //     (96 VGPRs) for the whole kernel -- the volume is the stationary operand, the queries stream;
+//   * the volume is F-major ([feature][voxel]), the B operand wants 8 consecutive FEATURES of one voxel per lane: the
+//     workgroup's [384][256] tile comes in by LDS-DMA as whole 512-byte feature rows (four parts of 96 rows through the
+//     two halves of the ring, 16-byte chunks XOR-swizzled by the row on the SOURCE side) and every wave picks its
+//     fragments up with ds_read_b64_tr_b16 (4 rows x 16 voxels per 16 lanes, conflict-free); volumes whose rows are not
+//     16-byte aligned (nvox % 8) fall back to 2-byte strided loads;
 //   * the queries are prepared once per call (sim_mfma_prep) as fp16 hi + lo halves (q = hi + lo to 2^-22; the
 //     volume is fp16 exactly, accumulation is fp32), padded per class to a multiple of 32 with zero rows (a zero
 //     query contributes where(0 >= 0.25) = 0) and stored in the LDS image order, so a 32-query chunk (48 KB) is
 //     a linear LDS-DMA copy into a 2-deep ring;
 //   * per chunk and wave 48 x v_mfma_f32_32x32x16_f16 (rows = queries, columns = voxels), then the activation and
-//     the in-lane sum over the 16 query rows a lane holds; one barrier per chunk.
+//     the in-lane sum over the 16 query rows a lane holds; one barrier per chunk;
+//   * the class table travels as a kernel argument (up to 32 classes; more: device tables filled by copies).
 #include "vittf_common.h"
 
 #include <stdlib.h>
@@ -23,13 +29,28 @@ constexpr int SM_F = 384, SM_KS = 24, SM_THREADS = 512, SM_VOX = 256;
 constexpr int SM_PART = 6 * 4096;       // one [32 queries][384] fp16 image: six [32][64] sub-images
 constexpr int SM_CHUNK = 2 * SM_PART;   // hi + lo: 48 KB
 
-// padded query p (class-major, each class padded to a multiple of 32) <- source row src_row[p] (-1: zero row)
-__global__ __launch_bounds__(256) void sim_mfma_prep(const float* __restrict__ qf, const int* __restrict__ src_row,
+constexpr int SM_MIN_A = 17;          // fewer annotations: the VALU kernels of similarity.hip (VITTF_SIM_MFMA_MIN overrides)
+constexpr int SM_MAXC = 32;
+struct SmClasses { int n; int start[SM_MAXC + 1]; };   // n = 0: the tables are in device memory instead
+
+// padded query p (class-major, each class padded to a multiple of 32) <- source row (-1: zero row): from the class table
+// in the argument, or from src_row[p] when there are more than SM_MAXC classes
+__global__ __launch_bounds__(256) void sim_mfma_prep(const float* __restrict__ qf, SmClasses cl, const int* __restrict__ src_row,
                                                      int padded, char* __restrict__ img) {
   const int e = blockIdx.x * 256 + threadIdx.x;          // one 16-byte chunk of one padded row
   if (e >= padded * 48) return;
   const int p = e / 48, c = e - 48 * p;
-  const int src = src_row[p];
+  int src = -1;
+  if (cl.n > 0) {
+    int p0 = 0;
+    for (int k = 0; k < cl.n; ++k) {
+      const int nk = cl.start[k + 1] - cl.start[k], pk = (nk + 31) & ~31;
+      if (p >= p0 && p < p0 + pk) src = p - p0 < nk ? cl.start[k] + (p - p0) : -1;
+      p0 += pk;
+    }
+  } else {
+    src = src_row[p];
+  }
   unsigned hi[4], lo[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -47,33 +68,81 @@ __global__ __launch_bounds__(256) void sim_mfma_prep(const float* __restrict__ q
 
 __device__ __forceinline__ float sm_thresh_pow(float s) { return s >= 0.25f ? s * s * sqrt_cr_normal(s) : 0.f; }   // (vittf_common.h: same bits as sqrtf, a third of its instructions)
 
+constexpr int SM_ROWS_PART = 96;                    // feature rows per staged part: 96 x 512 B = 48 KB = one half of the ring
+static_assert(SM_ROWS_PART * 512 == SM_CHUNK && SM_F % SM_ROWS_PART == 0, "a part of the volume tile fills one ring half");
+
+template <bool DMA>
 __global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned short* __restrict__ feat, int64_t nvox,
-                                                              const char* __restrict__ qimg,
+                                                              const char* __restrict__ qimg, SmClasses cl,
                                                               const int* __restrict__ chunk_start,
-                                                              const float* __restrict__ counts, int classes,
+                                                              const float* __restrict__ counts, int classes, int total,
                                                               const float* __restrict__ vnorm, float* __restrict__ sim,
                                                               unsigned* __restrict__ maxbits) {
   __shared__ __attribute__((aligned(16))) char ring[2 * SM_CHUNK];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int64_t v = (int64_t)blockIdx.x * SM_VOX + wave * 32 + l31;
+  const int64_t v0 = (int64_t)blockIdx.x * SM_VOX;
+  const int64_t v = v0 + wave * 32 + l31;
   const bool valid = v < nvox;
+  const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(ring);
 
   // the wave's 32 voxels x 384 features as B operands: xf[s] = features 16 s + 8 h .. + 7 of voxel v
   s16x8_t xf[SM_KS];
+  if constexpr (DMA) {
+    // Part p = feature rows 96 p .. 96 p + 95 of the workgroup's 256 voxels, 512 B per row, into ring half p & 1.  One
+    // DMA instruction of a wave = two rows (lanes 0-31 / 32-63): LDS position (lane & 31) of row r holds the row's 16-byte
+    // chunk (lane & 31) ^ 4 (r & 3) -- swizzled on the source side, the destination of an LDS-DMA is lane-linear -- so
+    // that the four rows of a transposing read sit on four different 64-byte bank groups.  A chunk beyond the end of
+    // the row (partial last workgroup) reads the row's last chunk instead: its voxels are never stored.
+    const int64_t last_chunk = nvox - 8;
+#define SM_STAGE_ROWS(P)                                                                                   \
+    {                                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                      \
+        const int r_ = 2 * (wave * 6 + i) + h;                                                             \
+        int64_t vs_ = v0 + 8 * (l31 ^ (4 * (r_ & 3)));                                                     \
+        vs_ = vs_ < last_chunk ? vs_ : last_chunk;                                                         \
+        lds_dma16_flat(feat + (int64_t)((P) * SM_ROWS_PART + r_) * nvox + vs_,                             \
+                       ring_lds + ((P) & 1) * SM_CHUNK + (wave * 6 + i) * 1024);                           \
+      }                                                                                                    \
+    }
+    // transposing read: 16-lane group g = lane >> 4 covers voxels 16 (g & 1) .. + 15 of the wave's 32 and k-group g >> 1;
+    // lane 4 q + pp of the group addresses row q, voxels 4 pp .. 4 pp + 3 (8 bytes); it receives 4 features of ITS voxel
+    const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int tr_chunk = (4 * (wave ^ qq)) | (2 * (grp & 1)) | (pp >> 1);       // swizzled 16-byte chunk of row (.. + qq)
+    const int tr_off = (8 * (grp >> 1) + qq) * 512 + tr_chunk * 16 + 8 * (pp & 1);
+    SM_STAGE_ROWS(0)
+    SM_STAGE_ROWS(1)
 #pragma unroll
-  for (int s = 0; s < SM_KS; ++s) {
-    s16x8_t t;
+    for (int p = 0; p < SM_F / SM_ROWS_PART; ++p) {
+      if (p + 1 < SM_F / SM_ROWS_PART) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // part p landed (6 pieces of p + 1 may be in flight)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      const char* buf = ring + (p & 1) * SM_CHUNK + tr_off;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = valid ? (short)feat[(int64_t)(16 * s + 8 * h + j) * nvox + v] : (short)0;
-    xf[s] = t;
+      for (int s = 0; s < SM_ROWS_PART / 16; ++s) {
+        const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s) * 512));
+        const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s + 4) * 512));
+        s16x8_t t;
+        t[0] = a[0]; t[1] = a[1]; t[2] = a[2]; t[3] = a[3]; t[4] = b[0]; t[5] = b[1]; t[6] = b[2]; t[7] = b[3];
+        xf[(SM_ROWS_PART / 16) * p + s] = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                      // everybody has read ring half p & 1
+      if (p + 2 < SM_F / SM_ROWS_PART) SM_STAGE_ROWS(p + 2)
+    }
+#undef SM_STAGE_ROWS
+  } else {
+#pragma unroll
+    for (int s = 0; s < SM_KS; ++s) {
+      s16x8_t t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = valid ? (short)feat[(int64_t)(16 * s + 8 * h + j) * nvox + v] : (short)0;
+      xf[s] = t;
+    }
   }
   const float nv = (vnorm && valid) ? vnorm[v] : 1.f;
 
-  const int total = chunk_start[classes];
   const i32x4_t rsrc = lds_dma_rsrc(qimg, (unsigned)((int64_t)total * SM_CHUNK < 0x7fffffff ? (int64_t)total * SM_CHUNK : 0x7fffffff));
-  const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(ring);
   const int voff = lane * 16;
   // chunk g -> ring[g & 1]: 48 pieces of 1 KB, 6 per wave
 #define SM_STAGE(G)                                                                                     \
@@ -85,9 +154,12 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned sho
   const int aoff0 = tile_off(l31, h);
   if (total > 0) SM_STAGE(0)
   int g = 0;
+  int g_end = 0;
   for (int c = 0; c < classes; ++c) {
     float csum = 0.f;
-    const int g_end = chunk_start[c + 1];
+    const int n_c = cl.n > 0 ? cl.start[c + 1] - cl.start[c] : 0;
+    g_end = cl.n > 0 ? g_end + ((n_c + 31) >> 5) : chunk_start[c + 1];
+    const float count = cl.n > 0 ? (float)n_c : counts[c];
     for (; g < g_end; ++g) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // chunk g landed; ring[(g + 1) & 1] is free
       if (g + 1 < total) SM_STAGE(g + 1)
@@ -114,7 +186,7 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned sho
     // the two lane halves hold the other 16 query rows of every chunk
     const unsigned cb = __float_as_uint(csum);
     const auto sw = __builtin_amdgcn_permlane32_swap(cb, cb, false, false);
-    const float mean = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) / counts[c];
+    const float mean = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) / count;
     if (valid && h == 0) sim[(int64_t)c * nvox + v] = mean;
     float m = valid ? mean : 0.f;
 #pragma unroll
@@ -132,37 +204,57 @@ size_t vittf_sim_mfma_workspace_bytes(int32_t classes, int32_t annotations) {
   return chunks * SM_CHUNK + ((chunks * 32 * 4 + 255) & ~(size_t)255) + (((size_t)classes + 1) * 8 + 255 & ~(size_t)255) + 256;
 }
 
+// does the matrix-core path take this query set?  (asked before the profiler scope is opened: an empty scope would count
+// as a launch of the class)
+bool vittf_sim_mfma_applies(int32_t f, int32_t classes, int32_t total_a, const void* ws, size_t ws_bytes) {
+  const char* e = getenv("VITTF_SIM_MFMA_MIN");   // (read per call: the tests switch it)
+  const int min_a = e ? atoi(e) : SM_MIN_A;
+  return f == SM_F && total_a >= min_a && ws && ws_bytes >= vittf_sim_mfma_workspace_bytes(classes, total_a);
+}
+
 // fp32 class maps [classes][nvox] + per-class maxima; returns 1 when this path does not apply
 int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, const float* qf, const int32_t* class_start_host,
                         int32_t classes, const float* voxel_norm, float* sim, unsigned* maxbits, void* ws, size_t ws_bytes,
                         hipStream_t st) {
   const int total_a = class_start_host[classes];
-  static const int min_a = [] { const char* e = getenv("VITTF_SIM_MFMA_MIN"); return e ? atoi(e) : 64; }();
-  if (f != SM_F || total_a < min_a) return 1;
-  if (!ws || ws_bytes < vittf_sim_mfma_workspace_bytes(classes, total_a)) return 1;
-  std::vector<int> src_row, chunk_start(classes + 1, 0);
-  std::vector<float> counts(classes);
-  for (int c = 0; c < classes; ++c) {
-    const int n = class_start_host[c + 1] - class_start_host[c];
-    counts[c] = (float)n;
-    for (int i = 0; i < ((n + 31) & ~31); ++i) src_row.push_back(i < n ? class_start_host[c] + i : -1);
-    chunk_start[c + 1] = (int)(src_row.size() / 32);
-  }
-  const int padded = (int)src_row.size();
-  const size_t chunks = (size_t)padded / 32;
+  if (!vittf_sim_mfma_applies(f, classes, total_a, ws, ws_bytes)) return 1;
+  SmClasses cl;
+  cl.n = classes <= SM_MAXC ? classes : 0;
+  for (int c = 0; c <= SM_MAXC; ++c) cl.start[c] = c <= classes && cl.n ? class_start_host[c] : 0;
+  size_t chunks = 0;
+  for (int c = 0; c < classes; ++c) chunks += (size_t)(class_start_host[c + 1] - class_start_host[c] + 31) / 32;
+  const int padded = (int)(chunks * 32);
   char* w = (char*)ws;
   char* img = w;
   int* src_d = (int*)(w + chunks * SM_CHUNK);
   int* chunk_d = (int*)((char*)src_d + (((size_t)padded * 4 + 255) & ~(size_t)255));
   float* counts_d = (float*)(chunk_d + classes + 1);
-  if (hipMemcpyAsync(src_d, src_row.data(), (size_t)padded * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(chunk_d, chunk_start.data(), ((size_t)classes + 1) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(counts_d, counts.data(), (size_t)classes * 4, hipMemcpyHostToDevice, st) != hipSuccess)
-    return VITTF_ERR_LAUNCH;
-  hipLaunchKernelGGL(sim_mfma_prep, dim3((padded * 48 + 255) / 256), dim3(256), 0, st, qf, src_d, padded, img);
+  std::vector<int> src_row, chunk_start;
+  std::vector<float> counts;
+  if (!cl.n) {   // more classes than the argument holds: the tables go through device memory
+    chunk_start.assign(classes + 1, 0);
+    counts.resize(classes);
+    for (int c = 0; c < classes; ++c) {
+      const int n = class_start_host[c + 1] - class_start_host[c];
+      counts[c] = (float)n;
+      for (int i = 0; i < ((n + 31) & ~31); ++i) src_row.push_back(i < n ? class_start_host[c] + i : -1);
+      chunk_start[c + 1] = (int)(src_row.size() / 32);
+    }
+    if (hipMemcpyAsync(src_d, src_row.data(), (size_t)padded * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(chunk_d, chunk_start.data(), ((size_t)classes + 1) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(counts_d, counts.data(), (size_t)classes * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+      return VITTF_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(sim_mfma_prep, dim3((padded * 48 + 255) / 256), dim3(256), 0, st, qf, cl, src_d, padded, img);
   const unsigned blocks = (unsigned)((nvox + SM_VOX - 1) / SM_VOX);
-  hipLaunchKernelGGL(sim_mfma_kernel, dim3(blocks), dim3(SM_THREADS), 0, st, feat, nvox, img, chunk_d, counts_d, classes,
-                     voxel_norm, sim, maxbits);
-  if (hipStreamSynchronize(st) != hipSuccess) return VITTF_ERR_LAUNCH;   // the host vectors above must outlive the copies
+  // whole-row LDS-DMA needs 16-byte aligned rows; other volumes take the strided loads
+  const bool dma = nvox % 8 == 0 && nvox >= 8 && ((uintptr_t)feat & 15) == 0;
+  if (dma)
+    hipLaunchKernelGGL(sim_mfma_kernel<true>, dim3(blocks), dim3(SM_THREADS), 0, st, feat, nvox, img, cl, chunk_d, counts_d, classes,
+                       (int)chunks, voxel_norm, sim, maxbits);
+  else
+    hipLaunchKernelGGL(sim_mfma_kernel<false>, dim3(blocks), dim3(SM_THREADS), 0, st, feat, nvox, img, cl, chunk_d, counts_d, classes,
+                       (int)chunks, voxel_norm, sim, maxbits);
+  if (!cl.n && hipStreamSynchronize(st) != hipSuccess) return VITTF_ERR_LAUNCH;   // the host vectors above must outlive the copies
   return vittf_check_launch();
 }
