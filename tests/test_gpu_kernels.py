@@ -657,6 +657,8 @@ def test_similarity_many_annotations_mfma_path(gpu, normalize):
 @pytest.mark.parametrize('grid,counts,min_a', [((7, 9, 11), (70, 3, 33), None),            # 693 voxels: rows not 16-byte aligned -> strided loads
                                                 ((16, 16, 16), (2,) * 40, None),              # 40 classes: tables through device memory
                                                 ((32, 32, 32), (16,), 8), ((24, 20, 18), (5, 1, 9), 8),   # few queries on the matrix cores
+                                                ((24, 20, 18), (30,), None),                  # one class, one chunk: the persistent kernel, partial last tile
+                                                ((48, 48, 50), (20,), None), ((64, 64, 64), (16,), 8),   # ... with 1-2 / 4 tiles per workgroup
                                                 ((64, 8, 8), (1024, 1024), None)])
 def test_similarity_mfma_path_shapes(gpu, monkeypatch, grid, counts, min_a):
     """The matrix-core similarity path on the shapes around its fast case: voxel counts whose feature rows cannot be

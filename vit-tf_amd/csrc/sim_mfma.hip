@@ -196,6 +196,101 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned sho
 #undef SM_STAGE
 }
 
+// The interactive query: ONE class of at most 32 annotations = one query chunk.  Persistent workgroups (one per CU) walk
+// the 256-voxel tiles; the chunk is fetched once per workgroup into its own 48 KB, and the volume stream never stops: while
+// a tile's last parts are read and its 48 MFMAs + activation run, the first two parts of the workgroup's next tile are
+// already in flight into the ring halves that tile has released (two parts = 96 KB per CU outstanding at all times).
+__global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned short* __restrict__ feat, int64_t nvox,
+                                                                  const char* __restrict__ qimg, float count, int ntiles,
+                                                                  const float* __restrict__ vnorm, float* __restrict__ sim,
+                                                                  unsigned* __restrict__ maxbits) {
+  __shared__ __attribute__((aligned(16))) char ring[2 * SM_CHUNK];
+  __shared__ __attribute__((aligned(16))) char qbuf[SM_CHUNK];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(ring);
+  const int64_t last_chunk = nvox - 8;
+  {   // the query chunk: 48 pieces of 1 KB, 6 per wave (issued first: the first counted wait below covers it)
+    const i32x4_t rsrc = lds_dma_rsrc(qimg, (unsigned)SM_CHUNK);
+    const unsigned q_lds = (unsigned)(size_t)LDS_PTR(qbuf);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lds_dma16(rsrc, q_lds + wave * 6144 + i * 1024, lane * 16, wave * 6144 + i * 1024);
+  }
+  // (layout, swizzle and the transposing read: sim_mfma_kernel above)
+#define SM_STAGE_ROWS(T, P)                                                                                \
+  {                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                        \
+      const int r_ = 2 * (wave * 6 + i) + h;                                                               \
+      int64_t vs_ = (int64_t)(T) * SM_VOX + 8 * (l31 ^ (4 * (r_ & 3)));                                    \
+      vs_ = vs_ < last_chunk ? vs_ : last_chunk;                                                           \
+      lds_dma16_flat(feat + (int64_t)((P) * SM_ROWS_PART + r_) * nvox + vs_,                               \
+                     ring_lds + ((P) & 1) * SM_CHUNK + (wave * 6 + i) * 1024);                             \
+    }                                                                                                      \
+  }
+  const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  const int tr_chunk = (4 * (wave ^ qq)) | (2 * (grp & 1)) | (pp >> 1);
+  const int tr_off = (8 * (grp >> 1) + qq) * 512 + tr_chunk * 16 + 8 * (pp & 1);
+  const int aoff0 = tile_off(l31, h);
+  int t = blockIdx.x;
+  const int stride = gridDim.x;
+  if (t < ntiles) { SM_STAGE_ROWS(t, 0) SM_STAGE_ROWS(t, 1) }
+  float wmax = 0.f;
+  for (; t < ntiles; t += stride) {
+    const bool more = t + stride < ntiles;
+    s16x8_t xf[SM_KS];
+#pragma unroll
+    for (int p = 0; p < SM_F / SM_ROWS_PART; ++p) {
+      // part p landed: at most the 6 pieces of the part issued after it may still be in flight (an older store of the
+      // previous tile only makes the wait conservative; the memory counter retires in order)
+      if (p == SM_F / SM_ROWS_PART - 1 && !more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      const char* buf = ring + (p & 1) * SM_CHUNK + tr_off;
+#pragma unroll
+      for (int s = 0; s < SM_ROWS_PART / 16; ++s) {
+        const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s) * 512));
+        const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s + 4) * 512));
+        s16x8_t x;
+        x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+        xf[(SM_ROWS_PART / 16) * p + s] = x;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // everybody has read ring half p & 1
+      if (p + 2 < SM_F / SM_ROWS_PART) SM_STAGE_ROWS(t, p + 2)
+      else if (more) SM_STAGE_ROWS(t + stride, p + 2 - SM_F / SM_ROWS_PART)
+    }
+    const int64_t v = (int64_t)t * SM_VOX + wave * 32 + l31;
+    const bool valid = v < nvox;
+    const float nv = (vnorm && valid) ? vnorm[v] : 1.f;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < SM_KS; ++s) {
+      const int off = (s >> 2) * 4096 + (aoff0 ^ (32 * (s & 3)));
+      const s16x8_t qh = *reinterpret_cast<const s16x8_t*>(qbuf + off);
+      const s16x8_t ql = *reinterpret_cast<const s16x8_t*>(qbuf + SM_PART + off);
+      acc = mfma32<VITTF_FP16>(qh, xf[s], acc);
+      acc = mfma32<VITTF_FP16>(ql, xf[s], acc);
+    }
+    float part0 = 0.f, part1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      part0 += sm_thresh_pow(vnorm ? acc[r] / nv : acc[r]);
+      part1 += sm_thresh_pow(vnorm ? acc[r + 1] / nv : acc[r + 1]);
+    }
+    const unsigned cb = __float_as_uint(part0 + part1);
+    const auto sw = __builtin_amdgcn_permlane32_swap(cb, cb, false, false);   // the other 16 query rows sit in the other lane half
+    const float mean = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) / count;
+    if (valid && h == 0) sim[v] = mean;
+    wmax = fmaxf(wmax, valid ? mean : 0.f);
+  }
+#undef SM_STAGE_ROWS
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+  if (lane == 0 && wmax > 0.f) atomicMax(maxbits, __float_as_uint(wmax));
+}
+
 }  // namespace
 
 size_t vittf_sim_mfma_workspace_bytes(int32_t classes, int32_t annotations) {
@@ -249,7 +344,11 @@ int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, con
   const unsigned blocks = (unsigned)((nvox + SM_VOX - 1) / SM_VOX);
   // whole-row LDS-DMA needs 16-byte aligned rows; other volumes take the strided loads
   const bool dma = nvox % 8 == 0 && nvox >= 8 && ((uintptr_t)feat & 15) == 0;
-  if (dma)
+  static const int cus = [] { int n = 0; return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess && n > 0 ? n : 256; }();
+  if (dma && cl.n == 1 && chunks == 1)   // the interactive query: one class, one chunk
+    hipLaunchKernelGGL(sim_mfma_few_kernel, dim3(blocks < (unsigned)cus ? blocks : (unsigned)cus), dim3(SM_THREADS), 0, st, feat, nvox, img,
+                       (float)total_a, (int)blocks, voxel_norm, sim, maxbits);
+  else if (dma)
     hipLaunchKernelGGL(sim_mfma_kernel<true>, dim3(blocks), dim3(SM_THREADS), 0, st, feat, nvox, img, cl, chunk_d, counts_d, classes,
                        (int)chunks, voxel_norm, sim, maxbits);
   else
