@@ -56,11 +56,13 @@ __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ sr
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       if constexpr (LDSOP) {
+        if (LDSOP != 3 || (m & 1))   // LDSOP = 3: half the fragment reads (one per two MFMAs + two transposing per four): 64 query rows per wave
         la[(m + 1) & 1] = *reinterpret_cast<const f16x8_t*>(lbase + 1024 * ((m + 1) & 3));      // operand of the NEXT MFMA
-        if constexpr (LDSOP == 2) {
-          if (m & 1) {
-            const s4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(lbase + 2048));
-            const s4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(lbase + 3072));
+        if constexpr (LDSOP >= 2) {      // transposing reads at an 8-byte lane stride: conflict-free (a 16-byte stride is 2-way)
+          const char* tbase = lds + (tid & 63) * 8 + (tid >> 6) * 4096;
+          if ((LDSOP == 2 && (m & 1)) || (LDSOP == 3 && (m & 3) == 3)) {
+            const s4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(tbase + 2048));
+            const s4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(tbase + 2560));
             trsink ^= t0 ^ t1;
           }
         }
@@ -165,6 +167,9 @@ int main() {
     run<4, 0, 1, 1>("bare MFMA, A operand by ds_read_b128", w, src, out, st);
     run<4, 1, 1, 1>("MFMA + softmax mix, A operand by ds_read_b128", w, src, out, st);
     run<4, 1, 1, 2>("MFMA + softmax mix, 12 LDS reads per 8 MFMAs", w, src, out, st);
+    run<4, 1, 1, 3>("MFMA + softmax mix, 6 LDS reads per 8 MFMAs", w, src, out, st);
+    run<4, 0, 1, 2>("bare MFMA, 12 LDS reads per 8 MFMAs", w, src, out, st);
+    run<4, 0, 1, 3>("bare MFMA, 6 LDS reads per 8 MFMAs", w, src, out, st);
     run<4, 2>("MFMA + 2 v_exp", w, src, out, st);
     run<4, 3>("MFMA + 1 v_exp", w, src, out, st);
     run<4, 4>("MFMA + 4 v_add + 1 v_cvt_pk", w, src, out, st);

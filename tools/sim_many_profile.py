@@ -21,6 +21,15 @@ def t(fn, reps=10):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 
+# the same call on volumes whose (query, voxel) similarities look like a segmentation task's: unit-norm features around 5
+# cluster centres (a query passes the 0.25 threshold on its own cluster's voxels only), and unit-norm noise (never)
+centres = torch.nn.functional.normalize(torch.randn(5, 384, generator=g), dim=1)
+which = torch.randint(0, 5, (64, 64, 64), generator=g)
+clustered = torch.nn.functional.normalize(centres[which].permute(3, 0, 1, 2) + 0.04 * torch.randn(384, 64, 64, 64, generator=g), dim=0).half().to(dev)
+noise = torch.nn.functional.normalize(torch.randn(384, 64, 64, 64, generator=g), dim=0).half().to(dev)
+for name, fv in (('clustered unit-norm features', clustered), ('unit-norm noise', noise)):
+    print(f'{name:30s}: {t(lambda: vt.compute_similarities(vol, fv, ann, keep_on_device=True)):.2f} ms (maps left on the GPU)')
+print('unnormalised Gaussian features (half of all dot products pass the threshold):')
 print(f'maps to the host      : {t(lambda: vt.compute_similarities(vol, feat, ann)):.2f} ms')
 print(f'maps left on the GPU  : {t(lambda: vt.compute_similarities(vol, feat, ann, keep_on_device=True)):.2f} ms')
 os.environ['VITTF_SIM_MFMA'] = '0'
