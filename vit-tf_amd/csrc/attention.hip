@@ -331,6 +331,8 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned s
 
 int vittf_attention_pipe(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
                          int32_t rows_per_wave, hipStream_t st);                                 // attention_pipe.hip
+int vittf_attention_rows64(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
+                           hipStream_t st);                                                        // attention_rows64.hip
 
 extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads,
                                int32_t dtype, int32_t q_prescaled, void* stream) {
@@ -349,6 +351,7 @@ extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_
     // VITTF_ATTN_PIPE=0: the round-1 lazy-maximum kernel below (0.844 ms).  Read per call: the tests switch it.
     const char* e = getenv("VITTF_ATTN_PIPE");
     const int pipe = e ? atoi(e) : 1;
+    if (pipe == 3) return vittf_attention_rows64(qkv, out, batch, tokens, heads, dtype, st);   // 64 rows per wave, two waves per SIMD
     if (pipe != 0) return vittf_attention_pipe(qkv, out, batch, tokens, heads, dtype, pipe == 1 ? 32 : 64, st);
   }
 #define VITTF_ATTN_LAUNCH(DTV, PREV)                                                                        \
