@@ -83,15 +83,24 @@ def _worker(rank, world, port, shape, fos, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('shape,fos', [((24, 16, 32), 3), ((10, 10, 10), 4)])
-def test_two_rank_sharding_matches_single_process_oracle(shape, fos):
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+# world 4 with 3 / 4 pooling windows per axis: uneven chunks, and (fos 3) a rank that owns no window at all -- the shape of
+# an 8-GPU run whose window count is not a multiple of the rank count
+@pytest.mark.parametrize('shape,fos,world', [((24, 16, 32), 3, 2), ((10, 10, 10), 4, 2), ((24, 16, 32), 3, 4), ((10, 10, 10), 4, 4)])
+def test_two_rank_sharding_matches_single_process_oracle(shape, fos, world):
     from oracle import feature_volume as ofv
     from helpers import tiny_model
     seed = 3
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + fos) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, fos, seed, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, fos, seed, q)) for r in range(world)]
     for p in procs:
         p.start()
     full, single = (torch.from_numpy(a) for a in q.get(timeout=300))
