@@ -317,10 +317,15 @@ def main():
     sim_bytes = nvox * (2 * dim + 4 * n_classes)             # fp16 feature row read once + fp32 class maps written
     sim_avg_ms = sim_k_ms / max(1, sim_k_n)
     sim_gbs = sim_bytes / (sim_avg_ms * 1e-3) / 1e9 if sim_avg_ms > 0 else 0.0
+    # one class of 17..32 queries over a 384-feature volume runs on the matrix cores (sim_mfma.hip: SM_MIN_A, one chunk); other
+    # widths (ViT-B: 768) and query counts take the VALU kernel
+    few = dim == 384 and int(os.environ.get('VITTF_SIM_MFMA_MIN', '17')) <= N_QUERIES <= 32 and os.environ.get('VITTF_SIM_MFMA', '1') != '0'
+    sim_kernel, sim_source = ('sim_mfma_few_kernel<fp16>', 'sim_mfma.hip') if few else ('sim_accumulate_split<fp16>', 'similarity.hip')
     roofline_sim = {
         'bound': 'hbm', 'achieved': round(sim_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-        'frac': round(sim_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc_traffic('similarity', N_QUERIES, 'similarity.hip', features=dim, nvox=nvox),
-        'kernel': 'sim_accumulate_split<fp16>', 'launches': int(sim_k_n), 'avg_launch_ms': round(sim_avg_ms, 5),
+        'frac': round(sim_gbs / PEAK_HBM_GBS, 4),
+        'traffic': pmc_traffic('similarity', N_QUERIES, sim_source, features=dim, nvox=nvox, kernel=sim_kernel),
+        'kernel': sim_kernel, 'launches': int(sim_k_n), 'avg_launch_ms': round(sim_avg_ms, 5),
         'bytes_per_launch': sim_bytes,
         'note': f'algorithmic bytes = Nvox * (2 D + 4 C) = {nvox} * (2*{dim} + 4*{n_classes}); the queries repeat over one resident '
                 f'{nvox * 2 * dim / 1e6:.0f} MB volume, so part of it is served by the 256 MB Infinity Cache (frac can exceed what HBM alone delivers)',

@@ -18,7 +18,9 @@ def main():
     rep = max(1, int(os.environ.get('VITTF_SIM_REPEAT', '1')))
     dev = torch.device('cuda', 0)
     g = torch.Generator().manual_seed(0)
-    feat = torch.nn.functional.normalize(torch.randn(384, fos, fos, fos, generator=g), dim=0).half().to(dev)
+    kind = os.environ.get('FEAT', 'unit')      # unit: unit-norm noise (no dot product reaches the 0.25 threshold); gauss: N(0, 1)
+    feat = torch.randn(384, fos, fos, fos, generator=g)            # features (every second one does); big: N(0, 1) x 8
+    feat = (torch.nn.functional.normalize(feat, dim=0) if kind == 'unit' else feat * (8 if kind == 'big' else 1)).half().to(dev)
     vol = torch.zeros(8 * fos, 8 * fos, 8 * fos, dtype=torch.float16)
     n_q = int(os.environ.get('QUERIES', '16'))
     ann = {'q': torch.randint(0, 8 * fos, (n_q, 3), generator=g)}
@@ -36,7 +38,7 @@ def main():
     vt._lib.profiler_enable(False)
     nbytes = feat.numel() * 2 + feat[0].numel() * 4
     per = ms / scopes / rep
-    print(f'fos {fos}, {n_q} queries, VITTF_SIM_MFMA_MIN={os.environ.get("VITTF_SIM_MFMA_MIN", "default")}: {rep} launch(es) per scope: {per * 1e3:.1f} us per launch by events ({nbytes / per / 1e6:.0f} GB/s algorithmic); '
+    print(f'{kind} features, fos {fos}, {n_q} queries, VITTF_SIM_MFMA_MIN={os.environ.get("VITTF_SIM_MFMA_MIN", "default")}: {rep} launch(es) per scope: {per * 1e3:.1f} us per launch by events ({nbytes / per / 1e6:.0f} GB/s algorithmic); '
           f'whole call {wall * 1e3:.3f} ms wall', flush=True)
 
 

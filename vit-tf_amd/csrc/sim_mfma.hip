@@ -197,11 +197,16 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned sho
 }
 
 // The interactive query: ONE class of at most 32 annotations = one query chunk.  Persistent workgroups (one per CU) walk
-// the 256-voxel tiles; the chunk is fetched once per workgroup into its own 48 KB, and the volume stream never stops: while
-// a tile's last parts are read and its 48 MFMAs + activation run, the first two parts of the workgroup's next tile are
-// already in flight into the ring halves that tile has released (two parts = 96 KB per CU outstanding at all times).
+// the 256-voxel tiles.  The queries are split into their fp16 hi + lo images by the workgroup itself (48 KB of LDS, once per
+// workgroup: no preparation launch), and the volume stream never stops: parts of 64 feature rows (32 KB) go round a
+// 3-deep ring with ONE barrier per part -- the barrier that publishes part p also says that everybody has finished reading
+// part p - 1, whose buffer takes part p + 2 -- so two parts (64 KB per CU) are in flight while a third is read, across
+// tile boundaries as well: a tile's 48 MFMAs + activation run under the first parts of the workgroup's next tile.
+constexpr int SM_FEW_ROWS = 64, SM_FEW_PART = SM_FEW_ROWS * 512, SM_FEW_PARTS = SM_F / SM_FEW_ROWS;   // 32 KB, 6 per tile
+static_assert(3 * SM_FEW_PART == 2 * SM_CHUNK && SM_FEW_PARTS % 3 == 0, "three parts fill the ring; a tile is a whole number of ring turns");
+
 __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned short* __restrict__ feat, int64_t nvox,
-                                                                  const char* __restrict__ qimg, float count, int ntiles,
+                                                                  const float* __restrict__ qf, int n_q, int ntiles,
                                                                   const float* __restrict__ vnorm, float* __restrict__ sim,
                                                                   unsigned* __restrict__ maxbits) {
   __shared__ __attribute__((aligned(16))) char ring[2 * SM_CHUNK];
@@ -211,53 +216,66 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
   const int h = lane >> 5, l31 = lane & 31;
   const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(ring);
   const int64_t last_chunk = nvox - 8;
-  {   // the query chunk: 48 pieces of 1 KB, 6 per wave (issued first: the first counted wait below covers it)
-    const i32x4_t rsrc = lds_dma_rsrc(qimg, (unsigned)SM_CHUNK);
-    const unsigned q_lds = (unsigned)(size_t)LDS_PTR(qbuf);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) lds_dma16(rsrc, q_lds + wave * 6144 + i * 1024, lane * 16, wave * 6144 + i * 1024);
-  }
-  // (layout, swizzle and the transposing read: sim_mfma_kernel above)
+  // (layout of a part, source-side swizzle and the transposing read: sim_mfma_kernel above; 4 DMA pieces per wave and part)
 #define SM_STAGE_ROWS(T, P)                                                                                \
   {                                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                        \
-      const int r_ = 2 * (wave * 6 + i) + h;                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+      const int r_ = 2 * (wave * 4 + i) + h;                                                               \
       int64_t vs_ = (int64_t)(T) * SM_VOX + 8 * (l31 ^ (4 * (r_ & 3)));                                    \
       vs_ = vs_ < last_chunk ? vs_ : last_chunk;                                                           \
-      lds_dma16_flat(feat + (int64_t)((P) * SM_ROWS_PART + r_) * nvox + vs_,                               \
-                     ring_lds + ((P) & 1) * SM_CHUNK + (wave * 6 + i) * 1024);                             \
+      lds_dma16_flat(feat + (int64_t)((P) * SM_FEW_ROWS + r_) * nvox + vs_,                                \
+                     ring_lds + ((P) % 3) * SM_FEW_PART + (wave * 4 + i) * 1024);                          \
     }                                                                                                      \
+  }
+  int t = blockIdx.x;
+  const int stride = gridDim.x;
+  if (t < ntiles) { SM_STAGE_ROWS(t, 0) SM_STAGE_ROWS(t, 1) }
+  // the query images (sim_mfma_prep's arithmetic): 32 rows x 48 chunks of 8 features, 3 chunks per thread; rows >= n_q are zero
+#pragma unroll
+  for (int e = tid; e < 32 * 48; e += SM_THREADS) {
+    const int p = e / 48, c = e - 48 * p;
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float q0 = 0.f, q1 = 0.f;
+      if (p < n_q) { q0 = qf[(int64_t)p * SM_F + 8 * c + 2 * j]; q1 = qf[(int64_t)p * SM_F + 8 * c + 2 * j + 1]; }
+      const unsigned short h0 = f32_to_f16bits(q0), h1 = f32_to_f16bits(q1);
+      const unsigned short l0 = f32_to_f16bits(q0 - f16bits_to_f32(h0)), l1 = f32_to_f16bits(q1 - f16bits_to_f32(h1));
+      hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+      lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+    char* dst = qbuf + (c >> 3) * 4096 + tile_off(p, c & 7);
+    *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(dst + SM_PART) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
   }
   const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
   const int tr_chunk = (4 * (wave ^ qq)) | (2 * (grp & 1)) | (pp >> 1);
   const int tr_off = (8 * (grp >> 1) + qq) * 512 + tr_chunk * 16 + 8 * (pp & 1);
   const int aoff0 = tile_off(l31, h);
-  int t = blockIdx.x;
-  const int stride = gridDim.x;
-  if (t < ntiles) { SM_STAGE_ROWS(t, 0) SM_STAGE_ROWS(t, 1) }
+  const float count = (float)n_q;
   float wmax = 0.f;
   for (; t < ntiles; t += stride) {
     const bool more = t + stride < ntiles;
     s16x8_t xf[SM_KS];
 #pragma unroll
-    for (int p = 0; p < SM_F / SM_ROWS_PART; ++p) {
-      // part p landed: at most the 6 pieces of the part issued after it may still be in flight (an older store of the
-      // previous tile only makes the wait conservative; the memory counter retires in order)
-      if (p == SM_F / SM_ROWS_PART - 1 && !more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-      const char* buf = ring + (p & 1) * SM_CHUNK + tr_off;
+    for (int p = 0; p < SM_FEW_PARTS; ++p) {
+      // part p landed: of everything issued after it only the 4 pieces of part p + 1 (and, conservatively counted, an older
+      // store of the previous tile) may still be in flight -- the memory counter retires in order.  The barrier also says
+      // that every wave has the fragments of part p - 1 in its registers (and, the first time, that the query images are
+      // written): its buffer is refilled right behind the barrier.
+      if (p == SM_FEW_PARTS - 1 && !more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (p + 2 < SM_FEW_PARTS) SM_STAGE_ROWS(t, p + 2)
+      else if (more) SM_STAGE_ROWS(t + stride, p + 2 - SM_FEW_PARTS)
+      const char* buf = ring + (p % 3) * SM_FEW_PART + tr_off;
 #pragma unroll
-      for (int s = 0; s < SM_ROWS_PART / 16; ++s) {
+      for (int s = 0; s < SM_FEW_ROWS / 16; ++s) {
         const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s) * 512));
         const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s + 4) * 512));
         s16x8_t x;
         x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
-        xf[(SM_ROWS_PART / 16) * p + s] = x;
+        xf[(SM_FEW_ROWS / 16) * p + s] = x;
       }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // everybody has read ring half p & 1
-      if (p + 2 < SM_F / SM_ROWS_PART) SM_STAGE_ROWS(t, p + 2)
-      else if (more) SM_STAGE_ROWS(t + stride, p + 2 - SM_F / SM_ROWS_PART)
     }
     const int64_t v = (int64_t)t * SM_VOX + wave * 32 + l31;
     const bool valid = v < nvox;
@@ -276,8 +294,10 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
     float part0 = 0.f, part1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      part0 += sm_thresh_pow(vnorm ? acc[r] / nv : acc[r]);
-      part1 += sm_thresh_pow(vnorm ? acc[r + 1] / nv : acc[r + 1]);
+      if (8 * (r >> 2) < n_q) {   // (registers 4 g .. 4 g + 3 are query rows 8 g .. 8 g + 7; rows >= n_q are zero queries: +0)
+        part0 += sm_thresh_pow(vnorm ? acc[r] / nv : acc[r]);
+        part1 += sm_thresh_pow(vnorm ? acc[r + 1] / nv : acc[r + 1]);
+      }
     }
     const unsigned cb = __float_as_uint(part0 + part1);
     const auto sw = __builtin_amdgcn_permlane32_swap(cb, cb, false, false);   // the other 16 query rows sit in the other lane half
@@ -340,15 +360,17 @@ int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, con
         hipMemcpyAsync(counts_d, counts.data(), (size_t)classes * 4, hipMemcpyHostToDevice, st) != hipSuccess)
       return VITTF_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(sim_mfma_prep, dim3((padded * 48 + 255) / 256), dim3(256), 0, st, qf, cl, src_d, padded, img);
   const unsigned blocks = (unsigned)((nvox + SM_VOX - 1) / SM_VOX);
   // whole-row LDS-DMA needs 16-byte aligned rows; other volumes take the strided loads
   const bool dma = nvox % 8 == 0 && nvox >= 8 && ((uintptr_t)feat & 15) == 0;
   static const int cus = [] { int n = 0; return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess && n > 0 ? n : 256; }();
-  if (dma && cl.n == 1 && chunks == 1)   // the interactive query: one class, one chunk
-    hipLaunchKernelGGL(sim_mfma_few_kernel, dim3(blocks < (unsigned)cus ? blocks : (unsigned)cus), dim3(SM_THREADS), 0, st, feat, nvox, img,
-                       (float)total_a, (int)blocks, voxel_norm, sim, maxbits);
-  else if (dma)
+  if (dma && cl.n == 1 && chunks == 1) {   // the interactive query: one class, one chunk; the kernel prepares the queries itself
+    hipLaunchKernelGGL(sim_mfma_few_kernel, dim3(blocks < (unsigned)cus ? blocks : (unsigned)cus), dim3(SM_THREADS), 0, st, feat, nvox,
+                       qf + (size_t)class_start_host[0] * SM_F, total_a, (int)blocks, voxel_norm, sim, maxbits);
+    return vittf_check_launch();
+  }
+  hipLaunchKernelGGL(sim_mfma_prep, dim3((padded * 48 + 255) / 256), dim3(256), 0, st, qf, cl, src_d, padded, img);
+  if (dma)
     hipLaunchKernelGGL(sim_mfma_kernel<true>, dim3(blocks), dim3(SM_THREADS), 0, st, feat, nvox, img, cl, chunk_d, counts_d, classes,
                        (int)chunks, voxel_norm, sim, maxbits);
   else
