@@ -317,9 +317,9 @@ def main():
     sim_bytes = nvox * (2 * dim + 4 * n_classes)             # fp16 feature row read once + fp32 class maps written
     sim_avg_ms = sim_k_ms / max(1, sim_k_n)
     sim_gbs = sim_bytes / (sim_avg_ms * 1e-3) / 1e9 if sim_avg_ms > 0 else 0.0
-    # one class of 17..32 queries over a 384-feature volume runs on the matrix cores (sim_mfma.hip: SM_MIN_A, one chunk); other
+    # one class of 8..32 queries over a 384-feature volume runs on the matrix cores (sim_mfma.hip: SM_MIN_A, one chunk); other
     # widths (ViT-B: 768) and query counts take the VALU kernel
-    few = dim == 384 and int(os.environ.get('VITTF_SIM_MFMA_MIN', '17')) <= N_QUERIES <= 32 and os.environ.get('VITTF_SIM_MFMA', '1') != '0'
+    few = dim == 384 and int(os.environ.get('VITTF_SIM_MFMA_MIN', '8')) <= N_QUERIES <= 32 and os.environ.get('VITTF_SIM_MFMA', '1') != '0'
     sim_kernel, sim_source = ('sim_mfma_few_kernel<fp16>', 'sim_mfma.hip') if few else ('sim_accumulate_split<fp16>', 'similarity.hip')
     roofline_sim = {
         'bound': 'hbm', 'achieved': round(sim_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',

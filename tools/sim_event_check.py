@@ -20,7 +20,7 @@ def main():
     g = torch.Generator().manual_seed(0)
     kind = os.environ.get('FEAT', 'unit')      # unit: unit-norm noise (no dot product reaches the 0.25 threshold); gauss: N(0, 1)
     feat = torch.randn(384, fos, fos, fos, generator=g)            # features (every second one does); big: N(0, 1) x 8
-    feat = (torch.nn.functional.normalize(feat, dim=0) if kind == 'unit' else feat * (8 if kind == 'big' else 1)).half().to(dev)
+    feat = (torch.nn.functional.normalize(feat, dim=0) * (16 if kind == 'unit16' else 1) if kind.startswith('unit') else feat * (8 if kind == 'big' else 1)).half().to(dev)   # unit16: the bits of 'unit' with the exponent shifted by 4 (dot products x 256: many pass)
     vol = torch.zeros(8 * fos, 8 * fos, 8 * fos, dtype=torch.float16)
     n_q = int(os.environ.get('QUERIES', '16'))
     ann = {'q': torch.randint(0, 8 * fos, (n_q, 3), generator=g)}

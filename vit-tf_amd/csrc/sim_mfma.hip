@@ -29,7 +29,7 @@ constexpr int SM_F = 384, SM_KS = 24, SM_THREADS = 512, SM_VOX = 256;
 constexpr int SM_PART = 6 * 4096;       // one [32 queries][384] fp16 image: six [32][64] sub-images
 constexpr int SM_CHUNK = 2 * SM_PART;   // hi + lo: 48 KB
 
-constexpr int SM_MIN_A = 17;          // fewer annotations: the VALU kernels of similarity.hip (VITTF_SIM_MFMA_MIN overrides)
+constexpr int SM_MIN_A = 8;           // fewer annotations: the VALU kernels of similarity.hip (VITTF_SIM_MFMA_MIN overrides)
 constexpr int SM_MAXC = 32;
 struct SmClasses { int n; int start[SM_MAXC + 1]; };   // n = 0: the tables are in device memory instead
 
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned sho
     float m = valid ? mean : 0.f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if (lane == 0 && m > 0.f) atomicMax(maxbits + c, __float_as_uint(m));
+    if (lane == 0) atomic_max_nonneg(maxbits + c, m);
   }
 #undef SM_STAGE
 }
@@ -254,6 +254,28 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
   const int aoff0 = tile_off(l31, h);
   const float count = (float)n_q;
   float wmax = 0.f;
+  // The activation of a tile (16 x the 2.5-th power per lane: VALU only) is spread over the part loop of the workgroup's
+  // NEXT tile, three values behind every part's fragment reads -- between two tiles' streams it cost 19 of 59 us.
+  f32x16_t pend;                      // the previous tile's dot products
+  int64_t pend_v = -1;                // its voxel (-1: nothing pending)
+  float pend_nv = 1.f, part0 = 0.f, part1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pend[r] = 0.f;
+  auto activate = [&](int r) {        // registers 4 g .. 4 g + 3 are query rows 8 g .. 8 g + 7; rows >= n_q are zero queries: +0
+    if (8 * (r >> 2) < n_q) {
+      const float a = sm_thresh_pow(vnorm ? pend[r] / pend_nv : pend[r]);
+      if (r & 1) part1 += a; else part0 += a;
+    }
+  };
+  auto finish = [&]() {
+    const unsigned cb = __float_as_uint(part0 + part1);
+    const auto sw = __builtin_amdgcn_permlane32_swap(cb, cb, false, false);   // the other 16 query rows sit in the other lane half
+    const float mean = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) / count;
+    const bool valid = pend_v < nvox;
+    if (valid && h == 0) sim[pend_v] = mean;
+    wmax = fmaxf(wmax, valid ? mean : 0.f);
+    part0 = 0.f; part1 = 0.f;
+  };
   for (; t < ntiles; t += stride) {
     const bool more = t + stride < ntiles;
     s16x8_t xf[SM_KS];
@@ -276,10 +298,14 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
         x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
         xf[(SM_FEW_ROWS / 16) * p + s] = x;
       }
+      if (pend_v >= 0) {              // (wave-uniform) the previous tile's values 3 p .. 3 p + 2; the last part takes value 15
+#pragma unroll
+        for (int r = 3 * p; r < (p == SM_FEW_PARTS - 1 ? 16 : 3 * p + 3); ++r) activate(r);
+      }
     }
+    if (pend_v >= 0) finish();
     const int64_t v = (int64_t)t * SM_VOX + wave * 32 + l31;
-    const bool valid = v < nvox;
-    const float nv = (vnorm && valid) ? vnorm[v] : 1.f;
+    pend_nv = (vnorm && v < nvox) ? vnorm[v] : 1.f;
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -291,24 +317,29 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
       acc = mfma32<VITTF_FP16>(qh, xf[s], acc);
       acc = mfma32<VITTF_FP16>(ql, xf[s], acc);
     }
-    float part0 = 0.f, part1 = 0.f;
+    pend = acc;
+    pend_v = v;
+  }
+  if (pend_v >= 0) {                  // the workgroup's last tile
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      if (8 * (r >> 2) < n_q) {   // (registers 4 g .. 4 g + 3 are query rows 8 g .. 8 g + 7; rows >= n_q are zero queries: +0)
-        part0 += sm_thresh_pow(vnorm ? acc[r] / nv : acc[r]);
-        part1 += sm_thresh_pow(vnorm ? acc[r + 1] / nv : acc[r + 1]);
-      }
-    }
-    const unsigned cb = __float_as_uint(part0 + part1);
-    const auto sw = __builtin_amdgcn_permlane32_swap(cb, cb, false, false);   // the other 16 query rows sit in the other lane half
-    const float mean = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) / count;
-    if (valid && h == 0) sim[v] = mean;
-    wmax = fmaxf(wmax, valid ? mean : 0.f);
+    for (int r = 0; r < 16; ++r) activate(r);
+    finish();
   }
 #undef SM_STAGE_ROWS
+  // ONE atomic per workgroup: the persistent workgroups all finish together, and 2048 wave-level atomics on one address
+  // took 18 us of a 59 us launch (the L2 serialises them at ~9 ns each)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
-  if (lane == 0 && wmax > 0.f) atomicMax(maxbits, __float_as_uint(wmax));
+  float* wm = reinterpret_cast<float*>(qbuf);          // (the query images are dead: every wave is past its last MFMA ...
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   //  ... once it is past this barrier)
+  if (lane == 0) wm[wave] = wmax;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (tid == 0) {
+    float m = wm[0];
+#pragma unroll
+    for (int w = 1; w < SM_THREADS / 64; ++w) m = fmaxf(m, wm[w]);
+    atomic_max_nonneg(maxbits, m);
+  }
 }
 
 }  // namespace

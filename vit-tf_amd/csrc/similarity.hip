@@ -224,7 +224,7 @@ __device__ __forceinline__ void sim_finish(float (&acc)[ACH][NV], int64_t v0, in
     if (last) {   // sims are >= 0, so the uint bit pattern orders like the float: one atomicMax per wave and class
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-      if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxbits + ch.c0 + c, __float_as_uint(m));
+      if ((threadIdx.x & 63) == 0) atomic_max_nonneg(maxbits + ch.c0 + c, m);
     }
   }
 }

@@ -111,6 +111,15 @@ __device__ __forceinline__ float sqrt_cr_normal(float x) {
   return y;
 }
 
+// Running maximum of non-negative floats kept as their bit pattern.  Workgroups that finish together would queue their
+// atomics on the one address (the L2 serialises them at ~9 ns each: 1024-2048 of them were 7-18 us of a 50 us similarity
+// launch); most of them carry a value the slot already exceeds, and a relaxed L2 read tells without queueing -- a stale
+// read only costs the atomic it would have saved.
+__device__ __forceinline__ void atomic_max_nonneg(unsigned* slot, float m) {
+  const unsigned bits = __float_as_uint(m);
+  if (m > 0.f && bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+}
+
 // ---- LDS-DMA hidden from hipcc -------------------------------------------------------------------------------
 // One piece: 64 lanes x 16 B -> 1 KB at LDS byte address lds_addr (lane-linear), fetched through a buffer descriptor
 // (bytes past num_records read as zeros).  hipcc orders every later ds_read / ds_write against an outstanding
