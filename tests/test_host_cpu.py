@@ -172,3 +172,30 @@ def test_sampler_oracle_is_the_scipy_restatement():
     s = osmp.sample_surface(lab.numpy(), 20)
     assert s.shape == (20, 3) and bool(shell[s[:, 0], s[:, 1], s[:, 2]].all())
     assert osmp.sample_both(lab.numpy(), 10).shape == (10, 3)
+
+
+def test_bench_flop_formula_matches_survey_figures():
+    """bench.vit_flops = SURVEY.md 8d's F_min: 444.9 GF per slice (ViT-S/8, N = 4097), 1211.2 GF (ViT-B/8), 5181.1 GF at
+    N = 16385 -- the numbers `roofline.achieved` is priced with."""
+    import bench
+    for (n, d, gf) in ((4097, 384, 444.9), (4097, 768, 1211.2), (16385, 384, 5181.1)):
+        total = sum(bench.vit_flops(n, d, 12, 8).values())
+        assert abs(total / 1e9 - gf) / gf < 5e-4, (n, d, total / 1e9)
+
+
+def test_bench_pmc_traffic_only_for_the_measured_kernel(tmp_path, monkeypatch):
+    """A committed PMC pass prices `roofline.traffic` only for the very kernel source, kernel and shape it was taken on."""
+    import json
+    import bench
+    (tmp_path / 'profiles').mkdir()
+    src = tmp_path / 'vit-tf_amd' / 'csrc'
+    src.mkdir(parents=True)
+    (src / 'k.hip').write_text('kernel v1')
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    rec = {'batch': 32, 'tokens': 4097, 'hbm_bytes_per_launch': 1000, 'source_sha1': bench.kernel_source_hash('k.hip')}
+    (tmp_path / 'profiles' / 'pmc_attention.json').write_text(json.dumps(rec))
+    assert bench.pmc_traffic('attention', 256, 'k.hip', tokens=4097) == 8000            # scales with the slices per launch
+    assert bench.pmc_traffic('attention', 256, 'k.hip', tokens=16385) is None           # another shape
+    assert bench.pmc_traffic('similarity', 16, 'k.hip') is None                          # no pass on file
+    (src / 'k.hip').write_text('kernel v2')
+    assert bench.pmc_traffic('attention', 256, 'k.hip', tokens=4097) is None            # the kernel changed since the pass
