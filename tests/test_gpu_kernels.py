@@ -656,6 +656,28 @@ def test_similarity_many_annotations_mfma_path(gpu, normalize):
         assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, (k, int(d.max()), float((d > 0).float().mean()))
 
 
+@pytest.mark.parametrize('grid,vol_shape', [((8, 8, 8), (64, 64, 64)), ((6, 7, 5), (60, 70, 64)), ((16, 16, 16), (34, 20, 96)),
+                                             ((8, 8, 8), (16, 16, 30))])
+def test_quantize_16_per_thread_matches_bytewise_kernel(gpu, monkeypatch, grid, vol_shape):
+    """The uint8 maps (quantise + nearest resize to vol.shape // 2, predict_ntf.py:95-100) from the 16-values-per-thread kernel
+    and from the one-byte-per-thread kernel are the same bytes: integer and non-integer resize ratios, two classes, wrapped
+    values, and an output row length the vector kernel does not take (15: both runs use the bytewise kernel)."""
+    g = gen(sum(grid) + sum(vol_shape))
+    feat = torch.nn.functional.normalize(torch.randn(64, *grid, generator=g), dim=0).half()
+    ann = {'a': torch.stack([torch.randint(0, s, (3,), generator=g) for s in vol_shape], 1),
+           'b': torch.stack([torch.randint(0, s, (2,), generator=g) for s in vol_shape], 1)}
+    vol = np.zeros(vol_shape, np.float32)
+    monkeypatch.setenv('VITTF_SIM_QUANT16', '1')
+    fast = vt.compute_similarities(vol, feat, ann)
+    monkeypatch.setenv('VITTF_SIM_QUANT16', '0')
+    slow = vt.compute_similarities(vol, feat, ann)
+    ref = osim.similarity_maps(vol_shape, feat.float(), ann)
+    for k in ann:
+        assert tuple(fast[k].shape) == tuple(s // 2 for s in vol_shape) and int(fast[k].max()) > 0
+        assert torch.equal(fast[k], slow[k]), k
+        assert float((fast[k] != ref[k]).float().mean()) <= 0.01
+
+
 @pytest.mark.parametrize('grid,counts,min_a', [((7, 9, 11), (70, 3, 33), None),            # 693 voxels: rows not 16-byte aligned -> strided loads
                                                 ((16, 16, 16), (2,) * 40, None),              # 40 classes: tables through device memory
                                                 ((32, 32, 32), (16,), 8), ((24, 20, 18), (5, 1, 9), 8),   # few queries on the matrix cores
