@@ -374,9 +374,10 @@ def test_pool_slices_bit_exact(gpu, axis, S, n_out, f0, f1):
 
 
 @pytest.mark.parametrize('world', [1, 2, 3])
-def test_assemble_sum_bit_exact(gpu, world):
+@pytest.mark.parametrize('n', [(5, 4, 7), (6, 5, 16), (8, 8, 64), (3, 7, 24)])   # the last dims 16 / 64: the 8-values-per-thread kernel when the z chunk allows
+def test_assemble_sum_bit_exact(gpu, world, n):
     lib = _lib.load()
-    d, n = 128, (5, 4, 7)
+    d = 128
     g = gen(world)
     vols = {ax: (torch.randn(d, *n, generator=g) * 8).half() for ax in 'zyx'}
     ref = ((0.0 + vols['z']) + vols['y']) + vols['x']            # fp16 adds, z -> y -> x (infer.py:330-332)

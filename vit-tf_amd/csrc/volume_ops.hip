@@ -111,6 +111,44 @@ __global__ __launch_bounds__(256) void assemble_sum_kernel(const unsigned short*
   }
 }
 
+// The same sum, 8 consecutive i2 per thread (n2 % 8 == 0 and the z chunk a multiple of 8: the three slabs and the output
+// are then 16-byte runs in i2), index split once per 8 values in 32-bit arithmetic: 0.63 -> ~0.2 ms for the 201 MB volume
+// (the scalar form spends nine 64-bit divisions per value).  Same arithmetic per value, same bits.
+__global__ __launch_bounds__(256) void assemble_sum8_kernel(const unsigned short* __restrict__ gz,
+                                                            const unsigned short* __restrict__ gy,
+                                                            const unsigned short* __restrict__ gx, int cz, int cy, int cx,
+                                                            int d, int n0, int n1, int n2, unsigned short* __restrict__ out) {
+  const int c2 = n2 >> 3;                                   // 8-value chunks per row
+  const int64_t chunks = (int64_t)d * n0 * n1 * c2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < chunks; e += (int64_t)gridDim.x * 256) {
+    const int64_t row = e / c2;                             // (f, i0, i1) flattened: < 2^31 (checked on the host)
+    const int i2 = 8 * (int)(e - row * c2);
+    const int r32 = (int)row;
+    const int f = r32 / (n0 * n1), r2 = r32 - f * (n0 * n1);
+    const int i0 = r2 / n1, i1 = r2 - i0 * n1;
+    const int rz = i2 / cz, rx = i0 / cx, ry = i1 / cy;
+    const int64_t oz = ((((int64_t)rz * d + f) * n0 + i0) * n1 + i1) * cz + (i2 - rz * cz);
+    const int64_t oy = ((((int64_t)ry * d + f) * n0 + i0) * cy + (i1 - ry * cy)) * n2 + i2;
+    const int64_t ox = ((((int64_t)rx * d + f) * cx + (i0 - rx * cx)) * n1 + i1) * n2 + i2;
+    const uint4 z4 = *reinterpret_cast<const uint4*>(gz + oz), y4 = *reinterpret_cast<const uint4*>(gy + oy),
+                x4 = *reinterpret_cast<const uint4*>(gx + ox);
+    const unsigned zw[4] = {z4.x, z4.y, z4.z, z4.w}, yw[4] = {y4.x, y4.y, y4.z, y4.w}, xw[4] = {x4.x, x4.y, x4.z, x4.w};
+    unsigned ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned w = 0;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const float z = f16bits_to_f32((unsigned short)(zw[k] >> (16 * hh))), y = f16bits_to_f32((unsigned short)(yw[k] >> (16 * hh))),
+                    x = f16bits_to_f32((unsigned short)(xw[k] >> (16 * hh)));
+        w |= (unsigned)f32_to_f16bits(f16_round(z + y) + x) << (16 * hh);     // one rounding per fp16 add, as above
+      }
+      ow[k] = w;
+    }
+    *reinterpret_cast<uint4*>(out + row * n2 + i2) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+}
+
 
 // ---- nearest resize of a uint8 volume (labels / class masks) and fp16 -> fp32 widening of an uploaded volume ----
 // F.interpolate(..., mode='nearest') on a 5-D tensor: src = min(floor(dst * (float)in / out), in - 1) per dim
@@ -211,8 +249,17 @@ extern "C" int vittf_assemble_sum(const uint16_t* gz, const uint16_t* gy, const 
   const int64_t total = (int64_t)d * n0 * n1 * n2;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(assemble_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gz, gy, gx,
-                     chunk[2], chunk[1], chunk[0], d, n0, n1, n2, out);
+  const bool vec = n2 % 8 == 0 && chunk[2] % 8 == 0 && (int64_t)d * n0 * n1 < 0x7fffffff &&
+                   (((uintptr_t)gz | (uintptr_t)gy | (uintptr_t)gx | (uintptr_t)out) & 15) == 0;
+  if (vec) {
+    blocks = (total / 8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(assemble_sum8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gz, gy, gx,
+                       chunk[2], chunk[1], chunk[0], d, n0, n1, n2, out);
+  } else {
+    hipLaunchKernelGGL(assemble_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gz, gy, gx,
+                       chunk[2], chunk[1], chunk[0], d, n0, n1, n2, out);
+  }
   return vittf_check_launch();
 }
 
