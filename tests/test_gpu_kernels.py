@@ -166,7 +166,7 @@ def _attn_ref(qkv, batch, tokens, heads, pre=0):
 
 
 # q as produced | pre-scaled q: software-pipelined kernel, 32 rows per wave (default) | its 64-rows-per-wave shape | round-1 kernel
-ATTN_VARIANTS = ['plain', 'pipe', 'pipe64', 'lazy', 'rows64']
+ATTN_VARIANTS = ['plain', 'pipe', 'pipe64', 'lazy', 'rows64', 'pingpong']
 
 
 def _attn_variant(variant):
@@ -178,6 +178,8 @@ def _attn_variant(variant):
         os.environ['VITTF_ATTN_PIPE'] = '2'
     elif variant == 'rows64':
         os.environ['VITTF_ATTN_PIPE'] = '3'
+    elif variant == 'pingpong':
+        os.environ['VITTF_ATTN_PIPE'] = '4'
     else:
         os.environ.pop('VITTF_ATTN_PIPE', None)
     return 0 if variant == 'plain' else 1

@@ -101,6 +101,14 @@ __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ sr
         pkprev = pk;
       } else if constexpr (FILL == 7) { // two v_exp_f16 only
         asm volatile("v_exp_f16 %0, %1\n\tv_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(pk2) : "v"(pkprev));
+      } else if constexpr (FILL == 9) { // the mix with its row sums as ONE v_dot2_f32_f16 of the packed pair: 2 v_exp + 1 v_cvt_pk + 1 v_dot2
+        asm volatile("v_exp_f32 %0, %4\n\tv_exp_f32 %1, %5\n\tv_cvt_pk_f16_f32 %2, %6, %7\n\tv_dot2_f32_f16 %3, %8, %9, %3"
+                     : "=&v"(ea0), "=&v"(ea1), "=&v"(pk), "+v"(s0) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1), "v"(pkprev), "v"(0x3c003c00u));
+        pkprev = pk;
+      } else if constexpr (FILL == 10) { // the same with the sum by v_dot2c_f32_f16 (VOP2 form, accumulates in place)
+        asm volatile("v_exp_f32 %0, %4\n\tv_exp_f32 %1, %5\n\tv_cvt_pk_f16_f32 %2, %6, %7\n\tv_dot2c_f32_f16 %3, %8, %9"
+                     : "=&v"(ea0), "=&v"(ea1), "=&v"(pk), "+v"(s0) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1), "v"(pkprev), "v"(0x3c003c00u));
+        pkprev = pk;
       } else if constexpr (FILL == 5) { // three plain VALU (the mix without its exps)
         asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_cvt_pk_f16_f32 %2, %3, %4"
                      : "+v"(s0), "+v"(s1), "=&v"(pk) : "v"(eb0), "v"(eb1));
@@ -175,6 +183,10 @@ int main() {
     run<4, 4>("MFMA + 4 v_add + 1 v_cvt_pk", w, src, out, st);
     run<4, 5>("MFMA + 2 v_add + 1 v_cvt_pk", w, src, out, st);
     run<4, 8>("MFMA + 2 v_exp + 1 v_cvt_pk + 1/2 mfma_4x4x4 (row sums)", w, src, out, st);
+    run<4, 9>("MFMA + 2 v_exp + 1 v_cvt_pk + 1 v_dot2_f32_f16", w, src, out, st);
+    run<4, 10>("MFMA + 2 v_exp + 1 v_cvt_pk + 1 v_dot2c_f32_f16", w, src, out, st);
+    run<4, 9, 0>("no MFMA: 2 v_exp + 1 v_cvt_pk + 1 v_dot2_f32_f16", w, src, out, st);
+    run<4, 10, 0>("no MFMA: 2 v_exp + 1 v_cvt_pk + 1 v_dot2c_f32_f16", w, src, out, st);
     run<4, 6>("MFMA + 1 v_cvt_pk + 2 v_exp_f16", w, src, out, st);
     run<4, 7>("MFMA + 2 v_exp_f16", w, src, out, st);
     run<4, 6, 0>("no MFMA: 1 v_cvt_pk + 2 v_exp_f16", w, src, out, st);

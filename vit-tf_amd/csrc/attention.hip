@@ -333,6 +333,8 @@ int vittf_attention_pipe(const void* qkv, void* out, int32_t batch, int32_t toke
                          int32_t rows_per_wave, hipStream_t st);                                 // attention_pipe.hip
 int vittf_attention_rows64(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
                            hipStream_t st);                                                        // attention_rows64.hip
+int vittf_attention_pp64(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
+                         hipStream_t st);                                                          // attention_pp64.hip
 
 extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads,
                                int32_t dtype, int32_t q_prescaled, void* stream) {
@@ -351,6 +353,7 @@ extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_
     // VITTF_ATTN_PIPE=0: the round-1 lazy-maximum kernel below (0.844 ms).  Read per call: the tests switch it.
     const char* e = getenv("VITTF_ATTN_PIPE");
     const int pipe = e ? atoi(e) : 1;
+    if (pipe == 4) return vittf_attention_pp64(qkv, out, batch, tokens, heads, dtype, st);     // two 32-row blocks per wave taking turns
     if (pipe == 3) return vittf_attention_rows64(qkv, out, batch, tokens, heads, dtype, st);   // 64 rows per wave, two waves per SIMD
     if (pipe != 0) return vittf_attention_pipe(qkv, out, batch, tokens, heads, dtype, pipe == 1 ? 32 : 64, st);
   }
