@@ -336,7 +336,7 @@ def main():
     if prof['mlp'][1] > 0:          # fused MLP: fc1 + fc2 in one kernel
         flop_slice['mlp'] = flop_slice.pop('gemm_fc1') + flop_slice.pop('gemm_fc2')
     flops = {k: v * slices_done for k, v in flop_slice.items()}
-    kernels = {'attention': ('attn_fp8_kernel (+ absmax + quantise)' if args.attention == 'fp8' else f'attn_pipe_kernel<{args.dtype}>'), 'gemm_qkv': f'gemm_ws_kernel<{args.dtype}, qkv>',
+    kernels = {'attention': ('attn_fp8_kernel (+ absmax + quantise)' if args.attention == 'fp8' else f'attn_pp64_kernel<{args.dtype}>'), 'gemm_qkv': f'gemm_ws_kernel<{args.dtype}, qkv>',
                'gemm_fc1': f'gemm_ws_kernel<{args.dtype}, fc1+gelu>', 'gemm_proj': f'gemm_rows_kernel<{args.dtype}, proj+ln>',
                'gemm_fc2': f'gemm_rows_kernel<{args.dtype}, fc2+ln>', 'gemm': f'gemm_kernel<{args.dtype}, kfeat>',
                'mlp': f'mlp_kernel<{args.dtype}>', 'patch_embed': 'patch_embed_kernel', 'layernorm': 'layernorm_kernel'}

@@ -165,23 +165,19 @@ def _attn_ref(qkv, batch, tokens, heads, pre=0):
     return (att.softmax(-1) @ v).transpose(1, 2).reshape(batch * tokens, d)
 
 
-# q as produced | pre-scaled q: software-pipelined kernel, 32 rows per wave (default) | its 64-rows-per-wave shape | round-1 kernel
-ATTN_VARIANTS = ['plain', 'pipe', 'pipe64', 'lazy', 'rows64', 'pingpong']
+# q as produced | pre-scaled q: two 32-row blocks per wave taking turns (default) | software-pipelined kernel, 32 rows per wave |
+# its 64-rows-per-wave shape | round-1 kernel | 64 rows per wave, compiler-scheduled
+ATTN_VARIANTS = ['plain', 'pingpong', 'pipe', 'pipe64', 'lazy', 'rows64']
 
 
 def _attn_variant(variant):
     """-> q_prescaled flag; selects the kernel behind vittf_attention(q_prescaled = 1) through its (per-call) switch."""
     import os
-    if variant == 'lazy':
-        os.environ['VITTF_ATTN_PIPE'] = '0'
-    elif variant == 'pipe64':
-        os.environ['VITTF_ATTN_PIPE'] = '2'
-    elif variant == 'rows64':
-        os.environ['VITTF_ATTN_PIPE'] = '3'
-    elif variant == 'pingpong':
-        os.environ['VITTF_ATTN_PIPE'] = '4'
-    else:
+    code = {'lazy': '0', 'pipe': '1', 'pipe64': '2', 'rows64': '3'}.get(variant)
+    if code is None:                         # 'plain' (its own kernel) and 'pingpong' (the default behind pre-scaled q)
         os.environ.pop('VITTF_ATTN_PIPE', None)
+    else:
+        os.environ['VITTF_ATTN_PIPE'] = code
     return 0 if variant == 'plain' else 1
 
 

@@ -348,12 +348,13 @@ extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_
   const float c = 0.125f * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)stream;
   if (q_prescaled && (dtype == VITTF_BF16 || dtype == VITTF_FP16)) {
-    // default for pre-scaled q: the software-pipelined kernel (attention_pipe.hip) in its 32-rows-per-wave, two-waves-per-
-    // SIMD shape (0.831 ms per launch in the pipeline); VITTF_ATTN_PIPE=2: 64 rows per wave, one wave per SIMD (0.998 ms);
-    // VITTF_ATTN_PIPE=0: the round-1 lazy-maximum kernel below (0.844 ms).  Read per call: the tests switch it.
+    // default for pre-scaled q (round 3): attention_pp64.hip, two 32-row query blocks per wave taking turns, two waves per SIMD
+    // (6.04 ms per 256-slice launch where the 32-row pipelined kernel takes 6.66).  VITTF_ATTN_PIPE=1: the software-pipelined
+    // 32-rows-per-wave kernel (attention_pipe.hip), 2: its 64-rows / one-wave-per-SIMD shape, 3: attention_rows64.hip,
+    // 0: the round-1 lazy-maximum kernel below.  Read per call: the tests switch it.
     const char* e = getenv("VITTF_ATTN_PIPE");
-    const int pipe = e ? atoi(e) : 1;
-    if (pipe == 4) return vittf_attention_pp64(qkv, out, batch, tokens, heads, dtype, st);     // two 32-row blocks per wave taking turns
+    const int pipe = e ? atoi(e) : 4;
+    if (pipe == 4) return vittf_attention_pp64(qkv, out, batch, tokens, heads, dtype, st);
     if (pipe == 3) return vittf_attention_rows64(qkv, out, batch, tokens, heads, dtype, st);   // 64 rows per wave, two waves per SIMD
     if (pipe != 0) return vittf_attention_pipe(qkv, out, batch, tokens, heads, dtype, pipe == 1 ? 32 : 64, st);
   }
