@@ -109,27 +109,37 @@ def query_voxels(label, n=N_QUERIES):
     return {'ntf1': idx[pick]}
 
 
-def kernel_source_hash(name):
-    """sha1 of a kernel source file: a committed PMC pass only describes the kernel it was measured on."""
-    with open(os.path.join(ROOT, 'vit-tf_amd', 'csrc', name), 'rb') as f:
-        return hashlib.sha1(f.read()).hexdigest()
+KERNEL_SOURCES = {     # what a kernel's code object is built from: its source, the shared headers and the Makefile's flags
+    'attention': ('attention_pp64.hip', 'attn_common.h', 'vittf_common.h', 'Makefile'),
+    'similarity': ('sim_mfma.hip', 'similarity.hip', 'vittf_common.h', 'Makefile'),
+}
 
 
-def pmc_traffic(kernel_class, batch, source, **shape):
+def kernel_source_hash(kernel_class):
+    """sha1 over everything the kernel of a class is compiled from: a committed PMC pass only describes the code object it
+    was measured on (a header or a flag change can add a spill, and with it HBM traffic)."""
+    h = hashlib.sha1()
+    for name in KERNEL_SOURCES[kernel_class]:
+        with open(os.path.join(ROOT, 'vit-tf_amd', 'csrc', name), 'rb') as f:
+            h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()
+
+
+def pmc_traffic(kernel_class, batch, **shape):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC pass (profiles/pmc_*.json: FETCH_SIZE doubled
     as MI355X_MICROARCH.md prescribes for gfx950 wide reads + WRITE_SIZE, separate passes).  The counters cannot be
-    collected from inside this process; null when no pass is on file for this very kernel source.  A launch works on
-    independent slices (queries), so the bytes of a pass taken at another batch size scale linearly with it."""
+    collected from inside this process; null when no pass is on file for this very code object, shape AND batch (the
+    pass is taken at the batch the engine runs: tools/pmc_attn.sh, tools/pmc_json.py)."""
     path = os.path.join(ROOT, 'profiles', f'pmc_{kernel_class}.json')
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if not rec.get('batch') or rec.get('source_sha1') != kernel_source_hash(source):
+    if rec.get('batch') != batch or rec.get('source_sha1') != kernel_source_hash(kernel_class):
         return None
     if any(rec.get(k) != v for k, v in shape.items()):      # a pass taken on another shape (heads, feature width) says nothing here
         return None
-    return int(rec['hbm_bytes_per_launch'] * batch / rec['batch'])
+    return int(rec['hbm_bytes_per_launch'])
 
 
 def host_cores():
@@ -222,14 +232,13 @@ def main():
     if args.fos != FOS:
         desc = desc.replace(f'fos {FOS}', f'fos {args.fos}').replace('512x512 (N=4097)', f'{8 * args.fos}x{8 * args.fos} (N={args.fos * args.fos + 1})') + ' [non-default --fos: not the metric\'s configuration]'
     sd = vt.synthetic_state_dict(args.arch, 0)
-    if args.engine_batch is None:
-        args.engine_batch = vt.extract.DEFAULT_ENGINE_BATCH
     model = vt.HipViT(sd, args.arch, args.dtype, device=dev, attention=args.attention)
     dim, depth, heads, patch = vt.ARCHS[args.arch]
     dvol = vt.DeviceVolume(vol, dev)                     # the input is resident in HBM before the timed region
     ann = query_voxels(label)
     im_sz, feat_out = vt.sizing(dvol.shape, args.fos, 8)
     n_tokens = (im_sz[0] // 8) * (im_sz[1] // 8) + 1
+    args.engine_batch = vt.extract.engine_batch_for(n_tokens, vt.ARCHS[args.arch][0], args.engine_batch)
     total_slices = sum(dvol.shape)
     my_slices = 0
     for sl in range(3):
@@ -314,21 +323,35 @@ def main():
     vt._lib.profiler_enable(False)
     nvox = feat_out[0] * feat_out[1] * feat_out[2]
     n_classes = len(ann)
-    sim_bytes = nvox * (2 * dim + 4 * n_classes)             # fp16 feature row read once + fp32 class maps written
+    sim_bytes = nvox * (2 * dim + n_classes)                 # the fp16 feature row read once + one map byte per class
     sim_avg_ms = sim_k_ms / max(1, sim_k_n)
     sim_gbs = sim_bytes / (sim_avg_ms * 1e-3) / 1e9 if sim_avg_ms > 0 else 0.0
-    # one class of 8..32 queries over a 384-feature volume runs on the matrix cores (sim_mfma.hip: SM_MIN_A, one chunk); other
-    # widths (ViT-B: 768) and query counts take the VALU kernel
-    few = dim == 384 and int(os.environ.get('VITTF_SIM_MFMA_MIN', '8')) <= N_QUERIES <= 32 and os.environ.get('VITTF_SIM_MFMA', '1') != '0'
-    sim_kernel, sim_source = ('sim_mfma_few_kernel<fp16>', 'sim_mfma.hip') if few else ('sim_accumulate_split<fp16>', 'similarity.hip')
+    sim_kernel = vt._lib.kernel_name('similarity')           # what the library's dispatcher launched, not a re-derivation
+    # the same query over three copies of the volume in turn (3 x 201 MB > the 256 MB Infinity Cache): every launch
+    # streams its volume from HBM -- the cold figure next to the cache-resident one above
+    copies = [feats] + [feats.clone() for _ in range(2)]
+    for c in copies:
+        vt.compute_similarities(vol, c, ann, keep_on_device=True)
+    torch.cuda.synchronize()
+    vt._lib.profiler_enable(True, classes=['similarity'])
+    for i in range(3 * 7):
+        vt.compute_similarities(vol, copies[i % 3], ann, keep_on_device=True)
+    torch.cuda.synchronize()
+    cold_ms, cold_n = vt._lib.profiler_collect()['similarity']
+    vt._lib.profiler_enable(False)
+    del copies
+    cold_avg_ms = cold_ms / max(1, cold_n)
+    cold_gbs = sim_bytes / (cold_avg_ms * 1e-3) / 1e9 if cold_avg_ms > 0 else 0.0
     roofline_sim = {
         'bound': 'hbm', 'achieved': round(sim_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
         'frac': round(sim_gbs / PEAK_HBM_GBS, 4),
-        'traffic': pmc_traffic('similarity', N_QUERIES, sim_source, features=dim, nvox=nvox, kernel=sim_kernel),
+        'traffic': pmc_traffic('similarity', N_QUERIES, features=dim, nvox=nvox, kernel=sim_kernel),
         'kernel': sim_kernel, 'launches': int(sim_k_n), 'avg_launch_ms': round(sim_avg_ms, 5),
         'bytes_per_launch': sim_bytes,
-        'note': f'algorithmic bytes = Nvox * (2 D + 4 C) = {nvox} * (2*{dim} + 4*{n_classes}); the queries repeat over one resident '
-                f'{nvox * 2 * dim / 1e6:.0f} MB volume, so part of it is served by the 256 MB Infinity Cache (frac can exceed what HBM alone delivers)',
+        'cold': {'achieved': round(cold_gbs, 1), 'frac': round(cold_gbs / PEAK_HBM_GBS, 4), 'avg_launch_ms': round(cold_avg_ms, 5),
+                 'launches': int(cold_n), 'note': 'the query rotating over three copies of the feature volume (603 MB): no launch finds its volume in the Infinity Cache'},
+        'note': f'algorithmic bytes = Nvox * (2 D + C) = {nvox} * (2*{dim} + {n_classes}); achieved / frac: the query repeats over ONE resident '
+                f'{nvox * 2 * dim / 1e6:.0f} MB volume, which the 256 MB Infinity Cache can serve in part -- "cold" is the HBM figure',
     }
 
     flop_slice = vit_flops(n_tokens, dim, depth, patch)
@@ -336,7 +359,7 @@ def main():
     if prof['mlp'][1] > 0:          # fused MLP: fc1 + fc2 in one kernel
         flop_slice['mlp'] = flop_slice.pop('gemm_fc1') + flop_slice.pop('gemm_fc2')
     flops = {k: v * slices_done for k, v in flop_slice.items()}
-    kernels = {'attention': ('attn_fp8_kernel (+ absmax + quantise)' if args.attention == 'fp8' else f'attn_pp64_kernel<{args.dtype}>'), 'gemm_qkv': f'gemm_ws_kernel<{args.dtype}, qkv>',
+    kernels = {'attention': f"{vt._lib.kernel_name('attention')}<{args.dtype}>", 'gemm_qkv': f'gemm_ws_kernel<{args.dtype}, qkv>',
                'gemm_fc1': f'gemm_ws_kernel<{args.dtype}, fc1+gelu>', 'gemm_proj': f'gemm_rows_kernel<{args.dtype}, proj+ln>',
                'gemm_fc2': f'gemm_rows_kernel<{args.dtype}, fc2+ln>', 'gemm': f'gemm_kernel<{args.dtype}, kfeat>',
                'mlp': f'mlp_kernel<{args.dtype}>', 'patch_embed': 'patch_embed_kernel', 'layernorm': 'layernorm_kernel'}
@@ -348,8 +371,9 @@ def main():
     vit_ms = sum(v[0] for k, v in prof.items() if k != 'similarity')
     roofline = {
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-        'traffic': pmc_traffic(dom, args.engine_batch if my_slices >= args.engine_batch else my_slices, 'attention_pipe.hip', tokens=n_tokens)
-        if (args.arch == 'vits8' and dom == 'attention' and args.attention == '16bit') else None,
+        'traffic': pmc_traffic(dom, args.engine_batch if my_slices >= args.engine_batch else my_slices, tokens=n_tokens, heads=heads,
+                               kernel=kernels[dom])
+        if (dom == 'attention' and args.attention == '16bit') else None,
         'kernel': kernels[dom],
         'launches': int(dom_launches), 'avg_launch_ms': round(dom_ms / max(1, dom_launches), 4),
         'flop_per_launch': flops[dom] / max(1, dom_launches),
@@ -366,7 +390,7 @@ def main():
             'value': round(args.steps * total_slices / elapsed, 2),
             'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
-            'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None,
+            'scaling': 'strong', 'vs_baseline': None,      # every N runs the same 512^3 volume: total work fixed, sharded over the ranks
             'dtype': args.dtype if args.attention == '16bit' else f'{args.dtype} (attention operands fp8 e4m3)', 'data': 'synthetic',
             'rccl_ranks': torch.distributed.get_world_size() if world > 1 else 1,
             'config': {'workload': desc, 'volume': list(dvol.shape), 'slices_per_step': total_slices,

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITTF_ABI_VERSION 2
+#define VITTF_ABI_VERSION 3
 
 typedef enum vittf_status {
   VITTF_OK = 0,
@@ -146,6 +146,9 @@ typedef enum vittf_kernel_class {
 } vittf_kernel_class;
 int vittf_profiler_enable(int32_t class_mask);
 int vittf_profiler_collect(double* ms_per_class, int64_t* launches_per_class);
+/* Name of the kernel the library's dispatcher launched LAST for a class that has several candidates (attention, similarity):
+ * "" if none was launched yet.  Static storage; never NULL. */
+const char* vittf_profiler_kernel_name(int32_t kernel_class);
 
 /* ------------------------------------------------------------------------------------------
  * Individual kernels, exported so that each one is parity-tested on its own (tests/).
@@ -205,10 +208,11 @@ int vittf_mlp_fused(const void* h, const void* w1, const float* b1, const void* 
 int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
                     int32_t q_prescaled, void* stream);
 
-/* Diagnostics (tools/ only): after a vittf_attention launch made with VITTF_ATTN_ABLATE=5 in the environment, the shader-
- * clock and 100 MHz real-time stamps the first waves took around their key loop: out_host[wave][4] = {clock start, clock
- * end, real-time start, real-time end}.  Synchronises the device; returns the number of waves copied (<= max_waves). */
-int vittf_debug_attention_stamps(uint64_t* out_host, int32_t max_waves);
+/* Statistics: how many times (per 32-row query block and 32-key half step) the pre-scaled kernel's lazy running maximum
+ * took its overflow branch (a row sum said the 16-bit P would overflow: true maximum, everything accumulated rescaled)
+ * since the counter was last reset.  Rare on trained weights; the tests use it to prove that a case drives the branch.
+ * Synchronises the device.  reset != 0 zeroes the counter after reading it. */
+int64_t vittf_attention_rescale_count(int32_t reset);
 
 /* fp8 attention (BASELINE configs[3]: "ViT-B/8 features, fp8 MFMA attention path").  Same contract as vittf_attention with
  * q_prescaled = 1, computed with OCP e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4: per (slice, head) power-of-two

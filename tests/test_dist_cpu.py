@@ -91,8 +91,11 @@ def _free_port():
 
 
 # world 4 with 3 / 4 pooling windows per axis: uneven chunks, and (fos 3) a rank that owns no window at all -- the shape of
-# an 8-GPU run whose window count is not a multiple of the rank count
-@pytest.mark.parametrize('shape,fos,world', [((24, 16, 32), 3, 2), ((10, 10, 10), 4, 2), ((24, 16, 32), 3, 4), ((10, 10, 10), 4, 4)])
+# an 8-GPU run whose window count is not a multiple of the rank count.  World 8: (512, 16, 16) at fos 2 has the benchmark's
+# own ratio along x -- 512 slices -> 64 windows of 8 slices -> 8 windows per rank -- while its y and z axes have 2 windows
+# for 8 ranks (six ranks contribute an empty slab); (80, 16, 16): 10 windows over 8 ranks, chunk 2, three ranks without one.
+@pytest.mark.parametrize('shape,fos,world', [((24, 16, 32), 3, 2), ((10, 10, 10), 4, 2), ((24, 16, 32), 3, 4), ((10, 10, 10), 4, 4),
+                                             ((512, 16, 16), 2, 8), ((80, 16, 16), 2, 8)])
 def test_two_rank_sharding_matches_single_process_oracle(shape, fos, world):
     from oracle import feature_volume as ofv
     from helpers import tiny_model

@@ -165,15 +165,14 @@ def _attn_ref(qkv, batch, tokens, heads, pre=0):
     return (att.softmax(-1) @ v).transpose(1, 2).reshape(batch * tokens, d)
 
 
-# q as produced | pre-scaled q: two 32-row blocks per wave taking turns (default) | software-pipelined kernel, 32 rows per wave |
-# its 64-rows-per-wave shape | round-1 kernel | 64 rows per wave, compiler-scheduled
-ATTN_VARIANTS = ['plain', 'pingpong', 'pipe', 'pipe64', 'lazy', 'rows64']
+# q as produced | pre-scaled q: two 32-row blocks per wave taking turns (default) | pre-scaled q: the round-1 lazy-maximum kernel
+ATTN_VARIANTS = ['plain', 'pingpong', 'lazy']
 
 
 def _attn_variant(variant):
     """-> q_prescaled flag; selects the kernel behind vittf_attention(q_prescaled = 1) through its (per-call) switch."""
     import os
-    code = {'lazy': '0', 'pipe': '1', 'pipe64': '2', 'rows64': '3'}.get(variant)
+    code = {'lazy': '0'}.get(variant)
     if code is None:                         # 'plain' (its own kernel) and 'pingpong' (the default behind pre-scaled q)
         os.environ.pop('VITTF_ATTN_PIPE', None)
     else:

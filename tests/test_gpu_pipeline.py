@@ -107,6 +107,35 @@ def test_vits8_full_size_slices(gpu, dt):
     assert e <= TOL[dt][0]
 
 
+def test_vits8_outlier_channels_full_size(gpu):
+    """The 16-bit operand path on weights with massive channels (vt.synthetic_state_dict(outliers=True): x50 residual-stream
+    channels, x50 LayerNorm gains, one head whose logits reach +-90 inside a row, one with logits up to ~130) instead of the
+    benign Gaussian ones every other parity test uses: ViT-S/8 at N = 4097, default dtype, against the CPU fp32 oracle.
+    Finite everywhere, inside the contract's 1e-3, and the lazy-maximum attention kernel demonstrably took its overflow
+    branch (the first key tile's maximum is far below what later keys reach in the planted head)."""
+    sd = vt.synthetic_state_dict('vits8', 0, outliers=True)
+    model = vt.HipViT(sd, 'vits8', 'fp16')
+    vol, _ = vt.synthetic_volume('torus_filled', 64, 0.1, 0)
+    vol = vol.float()
+    im_sz, _ = vt.sizing((64, 64, 64), 64, 8)
+    dvol = vt.DeviceVolume(vol, gpu)
+    lib = vt._lib.load()
+    lib.vittf_attention_rescale_count(1)
+    got = vt.k_slices(model, dvol, 'z', im_sz, 20, 21)[0].cpu()            # (4096, 384)
+    rescales = int(lib.vittf_attention_rescale_count(1))
+    oracle = dino_vit.build_vit('vits8', sd)
+    imgs = ofv.normalized_slices(vol, 'z')[[20]]
+    torch.set_num_threads(os.cpu_count() or 8)
+    with torch.no_grad():
+        ref = ofv.k_tokens(oracle, torch.nn.functional.interpolate(imgs, size=(512, 512), mode='nearest'))[0, 1:]
+    e = rel_fro(got, ref)
+    print(f'vits8 N=4097 fp16, outlier weights: rel fro {e:.3e}, max abs {max_abs(got, ref):.3e}, ref rms '
+          f'{float(ref.pow(2).mean().sqrt()):.3f}, overflow branch taken {rescales} times')
+    assert torch.isfinite(got.float()).all()
+    assert rescales > 0
+    assert e <= TOL['fp16'][0]
+
+
 def test_batching_and_sharding_do_not_change_bits(gpu):
     """Slices are independent: engine batch size and the split of pooling windows over ranks leave every bit alone."""
     sd = vt.synthetic_state_dict(TINY_ARCH, 5)
@@ -342,6 +371,16 @@ def test_fos128_long_sequence(gpu):
     e = rel_fro(got, ref)
     print(f'N=16385 depth-2 fp16: rel fro {e:.3e}')
     assert e <= TOL['fp16'][0]
+    # the same slice inside a full default engine batch for this token count (64 slices x 16385 rows: the row count and
+    # workspace of the 256 x 4097 headline shape; a batch of 256 here would be a 22 GB workspace with > 2^32-element buffers)
+    assert vt.extract.engine_batch_for(16385, 384) == 64
+    vol64 = torch.rand((16, 16, 70), generator=torch.Generator().manual_seed(7)).half().float()
+    vol64[:, :, 33] = vol[:, :, 1]
+    dv = vt.DeviceVolume(vol64, gpu)
+    one = vt.k_slices(model, dv, 'z', (1024, 1024, 70), 33, 34).cpu()
+    many = vt.k_slices(model, dv, 'z', (1024, 1024, 70), 0, 70)          # 64 + 6 slices: a full batch and a short one
+    assert torch.isfinite(many.float()).all()
+    assert torch.equal(many[33].cpu(), one[0])                            # bits do not depend on the batching
 
 
 def test_optional_paths_agree_with_default(gpu):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/vittf.h but not exported by libvittf.so'
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.vittf_abi_version() == vt._lib.ABI_VERSION == 2
+    assert lib.vittf_abi_version() == vt._lib.ABI_VERSION == 3
     assert lib.vittf_status_string(-2) == b'workspace too small'
 
 
@@ -199,3 +199,18 @@ def test_bench_pmc_traffic_only_for_the_measured_kernel(tmp_path, monkeypatch):
     assert bench.pmc_traffic('similarity', 16, 'k.hip') is None                          # no pass on file
     (src / 'k.hip').write_text('kernel v2')
     assert bench.pmc_traffic('attention', 256, 'k.hip', tokens=4097) is None            # the kernel changed since the pass
+
+
+def test_engine_batch_follows_a_workspace_budget(monkeypatch):
+    """Slices per engine call: 256 at the metric's shape, scaled down with the token count and the width so that the
+    workspace stays where 256 x 4097 x 384 puts it; an explicit request or VITTF_ENGINE_BATCH wins."""
+    from vit_tf_amd.extract import engine_batch_for
+    monkeypatch.delenv('VITTF_ENGINE_BATCH', raising=False)
+    assert engine_batch_for(4097, 384) == 256
+    assert engine_batch_for(16385, 384) == 64          # sub/infer_and_merge.sh: fos 128, 1024 x 1024 slices
+    assert engine_batch_for(4097, 768) == 128          # ViT-B/8
+    assert engine_batch_for(16385, 768) == 32
+    assert engine_batch_for(65, 384) == 256 and engine_batch_for(10 ** 9, 384) == 1
+    assert engine_batch_for(4097, 384, 32) == 32
+    monkeypatch.setenv('VITTF_ENGINE_BATCH', '8')
+    assert engine_batch_for(4097, 384, 32) == 8

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Interleaved A/B of attention kernel variants in ONE process on one device (the boxes of the pool differ by ~5 %, and
 separate invocations add more): rounds x variants, each timing `reps` back-to-back launches with events on the launch
-stream, on gaussian data.  Usage: python tools/attn_ab.py "1:0,4:0,4:1,4:5" [batch] [rounds]
-   variant = VITTF_ATTN_PIPE : VITTF_PP_VARIANT"""
+stream, on gaussian data.  Usage: python tools/attn_ab.py "1:0,0:0" [batch] [rounds]
+   variant = VITTF_ATTN_PIPE (0: the round-1 lazy-maximum kernel, anything else: the default) : VITTF_PP_VARIANT (a
+   build-time experiment switch, if the library under test reads one)"""
 import os
 import statistics
 import sys
@@ -16,7 +17,7 @@ from vit_tf_amd import _lib   # noqa: E402
 
 
 def main():
-    variants = [tuple(v.split(':')) for v in (sys.argv[1] if len(sys.argv) > 1 else '1:0,4:0').split(',')]
+    variants = [tuple(v.split(':')) for v in (sys.argv[1] if len(sys.argv) > 1 else '1:0,0:0').split(',')]
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
     tokens, heads, d = int(os.environ.get('TOKENS', '4097')), int(os.environ.get('HEADS', '6')), 64 * int(os.environ.get('HEADS', '6'))

@@ -27,12 +27,6 @@ for s in "$@"; do
               step rocprof 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 1 --warmup 1 --workload 64 --cpu-slices 0 ;;
     attn)     step test_attn 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider -k "attention or resize or widened or empty_class or single_annotation" ;;
     fullsize) step test_fullsize 1100 python -m pytest tests/test_gpu_fullsize.py -q -m gpu -s -p no:cacheprovider ;;
-    attnbench) for dt in fp16 bf16; do for pipe in 2 1 0; do
-                 DT=$dt VITTF_ATTN_PIPE=$pipe step attnbench_${dt}_pipe$pipe 300 python tools/bench_kernels.py attn; done; done ;;
-    ablate)   for a in 0 6 4 1 2; do DT=fp16 VITTF_ATTN_ABLATE=$a step ablate_$a 300 python tools/bench_kernels.py attn; done ;;
-    stamps)   step stamps 200 python tools/attn_stamps.py ;;
-    attnq)    step test_attnq 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider -k "attention and pipe" ;;
-    benchvar) for pipe in 2 1 0; do VITTF_BENCH_OVERLAP=0 VITTF_ATTN_PIPE=$pipe step benchvar_pipe$pipe 600 python bench.py --workload 256 --cpu-slices 0 --steps 3; done ;;
     ceiling)  step ceiling 240 tools/micro/mfma_ceiling ;;
     pmcattn)  step pmc_attn 900 bash tools/pmc_attn.sh attn ;;
     pmcsim)   step pmc_sim 600 bash tools/pmc_sim.sh ;;

@@ -61,6 +61,7 @@ SIGNATURES = {
                                        _vp, _vp, _sz, _vp]),
     'vittf_profiler_enable': (C.c_int, [_i32]),
     'vittf_profiler_collect': (C.c_int, [_P(C.c_double), _P(_i64)]),
+    'vittf_profiler_kernel_name': (C.c_char_p, [_i32]),
     'vittf_patch_embed': (C.c_int, [_P(VitConfig), _P(VitWeights), _P(PosEmbed), _P(SliceView), _i32, _i32, _vp, _vp]),
     'vittf_layernorm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, C.c_float, _i32, _vp]),
     'vittf_gemm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -68,7 +69,7 @@ SIGNATURES = {
     'vittf_ln_gemm': (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'vittf_mlp_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    'vittf_debug_attention_stamps': (C.c_int, [_P(C.c_uint64), _i32]),
+    'vittf_attention_rescale_count': (_i64, [_i32]),
     'vittf_attention_fp8_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'vittf_attention_fp8': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     'vittf_pool_slices': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64,
@@ -121,7 +122,7 @@ def load():
 
 KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention', 'mlp', 'gemm_qkv', 'gemm_proj', 'gemm_fc1', 'gemm_fc2',
                   'similarity')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def profiler_enable(on=True, classes=None):
@@ -130,6 +131,11 @@ def profiler_enable(on=True, classes=None):
     if on:
         mask = -1 if classes is None else sum(1 << KERNEL_CLASSES.index(c) for c in classes)
     check(load().vittf_profiler_enable(mask), 'vittf_profiler_enable')
+
+
+def kernel_name(kernel_class):
+    """Name of the kernel the library launched last for 'attention' / 'similarity' ('' if none yet)."""
+    return load().vittf_profiler_kernel_name(KERNEL_CLASSES.index(kernel_class)).decode()
 
 
 def profiler_collect():

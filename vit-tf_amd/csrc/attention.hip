@@ -329,10 +329,6 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned s
 
 }  // namespace
 
-int vittf_attention_pipe(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
-                         int32_t rows_per_wave, hipStream_t st);                                 // attention_pipe.hip
-int vittf_attention_rows64(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
-                           hipStream_t st);                                                        // attention_rows64.hip
 int vittf_attention_pp64(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
                          hipStream_t st);                                                          // attention_pp64.hip
 
@@ -349,18 +345,18 @@ extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_
   hipStream_t st = (hipStream_t)stream;
   if (q_prescaled && (dtype == VITTF_BF16 || dtype == VITTF_FP16)) {
     // default for pre-scaled q (round 3): attention_pp64.hip, two 32-row query blocks per wave taking turns, two waves per SIMD
-    // (6.04 ms per 256-slice launch where the 32-row pipelined kernel takes 6.66).  VITTF_ATTN_PIPE=1: the software-pipelined
-    // 32-rows-per-wave kernel (attention_pipe.hip), 2: its 64-rows / one-wave-per-SIMD shape, 3: attention_rows64.hip,
-    // 0: the round-1 lazy-maximum kernel below.  Read per call: the tests switch it.
+    // (6.04 ms per 256-slice launch where round 2's 32-rows-per-wave pipelined kernel took 6.66).  VITTF_ATTN_PIPE=0: the
+    // round-1 lazy-maximum kernel below (read per call: the tests switch it).
     const char* e = getenv("VITTF_ATTN_PIPE");
-    const int pipe = e ? atoi(e) : 4;
-    if (pipe == 4) return vittf_attention_pp64(qkv, out, batch, tokens, heads, dtype, st);
-    if (pipe == 3) return vittf_attention_rows64(qkv, out, batch, tokens, heads, dtype, st);   // 64 rows per wave, two waves per SIMD
-    if (pipe != 0) return vittf_attention_pipe(qkv, out, batch, tokens, heads, dtype, pipe == 1 ? 32 : 64, st);
+    if (!e || atoi(e) != 0) {
+      vittf_note_kernel(VITTF_KERNEL_ATTENTION, "attn_pp64_kernel");
+      return vittf_attention_pp64(qkv, out, batch, tokens, heads, dtype, st);
+    }
   }
 #define VITTF_ATTN_LAUNCH(DTV, PREV)                                                                        \
   hipLaunchKernelGGL((attn_kernel<DTV, PREV>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,   \
                      (unsigned short*)out, tokens, heads, q_tiles, total, c)
+  vittf_note_kernel(VITTF_KERNEL_ATTENTION, q_prescaled ? "attn_kernel<lazy maximum>" : "attn_kernel<online maximum>");
   if (dtype == VITTF_BF16) {
     if (q_prescaled) VITTF_ATTN_LAUNCH(VITTF_BF16, true); else VITTF_ATTN_LAUNCH(VITTF_BF16, false);
   } else if (dtype == VITTF_FP16) {

@@ -329,6 +329,7 @@ extern "C" size_t vittf_attention_fp8_workspace_bytes(int32_t batch, int32_t tok
 
 extern "C" int vittf_attention_fp8(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
                                    void* ws, size_t ws_bytes, void* stream) {
+  vittf_note_kernel(VITTF_KERNEL_ATTENTION, "attn_fp8_kernel (+ absmax + quantise)");
   if (!qkv || !out || !ws || batch <= 0 || tokens <= 0 || heads <= 0) return VITTF_ERR_INVALID_ARG;
   if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
   if (((uintptr_t)ws & 255) != 0) return VITTF_ERR_INVALID_ARG;

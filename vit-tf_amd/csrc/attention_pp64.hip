@@ -2,7 +2,7 @@
 // ("ping-pong"), two waves per SIMD.  Same contract as attention.hip (softmax(q k^T / 8) v per head; Attention.forward of
 // the upstream model the reference calls, infer.py:177), same LDS images, same lazy running maximum.
 //
-// What the 32-rows-per-wave pipelined kernel (attention_pipe.hip) pays per MFMA besides the softmax arithmetic is operand
+// What a 32-rows-per-wave kernel (round 2's software-pipelined attention_pipe.hip, 0.40 of peak) pays per MFMA besides the softmax arithmetic is operand
 // delivery and synchronisation: 12 LDS fragment instructions, half a barrier and 2 LDS-DMA issues per 8 MFMAs.  Here every
 // K / V^T fragment feeds the MFMAs of both blocks of the wave, and a 64-key tile serves 256 query rows of the workgroup:
 // all three halve.  The software pipeline needs no second score tile either -- the two blocks ARE the two stages:
@@ -69,6 +69,10 @@ __device__ __forceinline__ float tile_max(const f32x16_t& s) {
   return max3_f32(tmax, __uint_as_float(sw[0]), __uint_as_float(sw[1]));      // both lane halves agree
 }
 
+// executions of the overflow branch (statistics, vittf_attention_rescale_count): one relaxed atomic per execution, on a
+// path that real weights take a handful of times per launch
+__device__ unsigned g_rescales;
+
 template <int DT> __device__ __forceinline__ constexpr float p_limit() { return DT == VITTF_FP16 ? 8192.f : 1073741824.f; }
 
 // The slow path of a phase: block X's values have outgrown the 16-bit P at its current M.  Raw scores of the half step
@@ -77,6 +81,7 @@ template <int DT> __device__ __forceinline__ constexpr float p_limit() { return 
 template <int DT>
 __device__ __forceinline__ float rescale_block(const LdsBases& b, Blk& X, const QFrag& qX, s16x8_t (&pX)[2], int ck_off, bool mask,
                                                int key0, int tokens, int h) {
+  if ((threadIdx.x & 63) == 0) atomicAdd(&g_rescales, 1u);
   f32x16_t raw;
 #pragma unroll
   for (int r = 0; r < 16; ++r) raw[r] = 0.f;
@@ -159,7 +164,7 @@ __device__ __forceinline__ void pp_phase(const LdsBases& b, Blk& X, const QFrag&
 
 // The same phase with RUN-TIME ring offsets and flags, for the tiles outside the steady-state loop (the first tile, the up to
 // two tiles the 3-tile loop leaves over, the ragged last tile): a handful of executions per workgroup, nothing pinned, ONE
-// code path instead of a template instance per combination (attention_pipe.hip: seven instances spilled ~110 registers).
+// code path instead of a template instance per combination (round 2: seven instances spilled ~110 registers).
 template <int DT>
 __device__ __forceinline__ void pp_phase_rt(const LdsBases& b, Blk& X, const QFrag& qX, f32x16_t& sX, s16x8_t (&pX)[2], Blk& Y,
                                             const QFrag& qY, f32x16_t& sY, const s16x8_t (&pY)[2], KFrag& kf, VFrag& vf,
@@ -257,9 +262,11 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(const unsigned short*
     const int so_ = (t_) * tile_stride;                                                             \
     const unsigned dst_ = dma_dst + (bufi_) * BUFB;                                                 \
     if ((t_) == nt - 1) {                                                                           \
+      int vk_ = voff_k, vv_ = voff_v;   /* opaque copies: the sums below are formed here, not kept alive through the loop */ \
+      asm volatile("" : "+v"(vk_), "+v"(vv_));                                                      \
       _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                            \
-        lds_dma16(rsrc, dst_ + i_ * 4096, voff_k + so_ + i_ * half_stride, 0);                      \
-        lds_dma16(rsrc, dst_ + KVB + i_ * 4096, voff_v + so_ + i_ * half_stride, 0);                \
+        lds_dma16(rsrc, dst_ + i_ * 4096, vk_ + so_ + i_ * half_stride, 0);                         \
+        lds_dma16(rsrc, dst_ + KVB + i_ * 4096, vv_ + so_ + i_ * half_stride, 0);                   \
       }                                                                                             \
     } else {                                                                                        \
       _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                            \
@@ -354,13 +361,19 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(const unsigned short*
   {                                                                                                                         \
     const int o_ = (t % NBUF) * BUFB, on_ = ((t + 1) % NBUF) * BUFB;                                                        \
     const bool first_ = t == 0, last_ = t == nt - 1;                                                                        \
-    pp_phase_rt<DT>(b, A, qa, sa, pa, B, qb, sb, pb, kf, vf, o_, o_ + 4096, o_ + KVB, !first_, !first_, true, true, last_,   \
-                    t * KT, tokens, h);                                                                                     \
-    pp_phase_rt<DT>(b, B, qb, sb, pb, A, qa, sa, pa, kf, vf, o_, 0, 0, true, true, false, false, last_, t * KT, tokens, h);  \
-    pp_phase_rt<DT>(b, A, qa, sa, pa, B, qb, sb, pb, kf, vf, o_ + 4096, on_, o_ + KVB + 4096, true, true, !last_, true,      \
-                    last_, t * KT + 32, tokens, h);                                                                         \
-    pp_phase_rt<DT>(b, B, qb, sb, pb, A, qa, sa, pa, kf, vf, o_ + 4096, 0, 0, !last_, true, false, false, last_,             \
-                    t * KT + 32, tokens, h);                                                                                \
+    /* a last tile of at most 32 keys (the CLS token's: N = 64 x 64 + 1) ends after its first half step */                  \
+    const bool half_ = last_ && tokens - t * KT <= 32;                                                                      \
+    int hc_ = h;       /* opaque: the masks' per-lane key indices are formed per tile, not carried through the loop */      \
+    asm volatile("" : "+v"(hc_));                                                                                           \
+    pp_phase_rt<DT>(b, A, qa, sa, pa, B, qb, sb, pb, kf, vf, o_, o_ + 4096, o_ + KVB, !first_, !first_, !half_, true, last_, \
+                    t * KT, tokens, hc_);                                                                                     \
+    pp_phase_rt<DT>(b, B, qb, sb, pb, A, qa, sa, pa, kf, vf, o_, 0, 0, !half_, true, false, false, last_, t * KT, tokens, hc_); \
+    if (!half_) {                                                                                                           \
+      pp_phase_rt<DT>(b, A, qa, sa, pa, B, qb, sb, pb, kf, vf, o_ + 4096, on_, o_ + KVB + 4096, true, true, !last_, true,    \
+                      last_, t * KT + 32, tokens, hc_);                                                                       \
+      pp_phase_rt<DT>(b, B, qb, sb, pb, A, qa, sa, pa, kf, vf, o_ + 4096, 0, 0, !last_, true, false, false, last_,           \
+                      t * KT + 32, tokens, hc_);                                                                              \
+    }                                                                                                                       \
     ++t;                                                                                                                    \
   }
   int t = 0;
@@ -410,6 +423,17 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(const unsigned short*
 }
 
 }  // namespace
+
+extern "C" int64_t vittf_attention_rescale_count(int32_t reset) {
+  unsigned v = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return VITTF_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_rescales), sizeof(v)) != hipSuccess) return VITTF_ERR_LAUNCH;
+  if (reset) {
+    const unsigned z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rescales), &z, sizeof(z)) != hipSuccess) return VITTF_ERR_LAUNCH;
+  }
+  return (int64_t)v;
+}
 
 // C++ linkage: called by vittf_attention (attention.hip) for q_prescaled = 1
 int vittf_attention_pp64(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype, hipStream_t st) {

@@ -211,6 +211,14 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   return VITTF_OK;
 }
 
+static const char* g_kernel_names[VITTF_KERNEL_CLASSES] = {};
+void vittf_note_kernel(int cls, const char* name) {
+  if (cls >= 0 && cls < VITTF_KERNEL_CLASSES) g_kernel_names[cls] = name;
+}
+extern "C" const char* vittf_profiler_kernel_name(int32_t cls) {
+  return (cls >= 0 && cls < VITTF_KERNEL_CLASSES && g_kernel_names[cls]) ? g_kernel_names[cls] : "";
+}
+
 extern "C" int vittf_profiler_enable(int32_t on) {
   for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
   g_prof_recs.clear();

@@ -394,12 +394,19 @@ int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, con
   const unsigned blocks = (unsigned)((nvox + SM_VOX - 1) / SM_VOX);
   // whole-row LDS-DMA needs 16-byte aligned rows; other volumes take the strided loads
   const bool dma = nvox % 8 == 0 && nvox >= 8 && ((uintptr_t)feat & 15) == 0;
-  static const int cus = [] { int n = 0; return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess && n > 0 ? n : 256; }();
+  // CUs of the CURRENT device (one process per GPU: the rank's device, not device 0), asked once
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
+  }();
   if (dma && cl.n == 1 && chunks == 1) {   // the interactive query: one class, one chunk; the kernel prepares the queries itself
+    vittf_note_kernel(VITTF_KERNEL_SIMILARITY, "sim_mfma_few_kernel");
     hipLaunchKernelGGL(sim_mfma_few_kernel, dim3(blocks < (unsigned)cus ? blocks : (unsigned)cus), dim3(SM_THREADS), 0, st, feat, nvox,
                        qf + (size_t)class_start_host[0] * SM_F, total_a, (int)blocks, voxel_norm, sim, maxbits);
     return vittf_check_launch();
   }
+  vittf_note_kernel(VITTF_KERNEL_SIMILARITY, "sim_mfma_kernel");
   hipLaunchKernelGGL(sim_mfma_prep, dim3((padded * 48 + 255) / 256), dim3(256), 0, st, qf, cl, src_d, padded, img);
   if (dma)
     hipLaunchKernelGGL(sim_mfma_kernel<true>, dim3(blocks), dim3(SM_THREADS), 0, st, feat, nvox, img, cl, chunk_d, counts_d, classes,

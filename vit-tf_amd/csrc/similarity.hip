@@ -536,16 +536,12 @@ int accumulate_class_maps(const void* feat, bool half, int32_t f, int64_t nvox, 
                             voxel_norm, expo, sim, maxbits);                                                             \
   }
     {
-      // VITTF_SIM_REPEAT=n (timing diagnostic, tools/sim_event_check.py): the same launch n times inside one profiler
-      // scope -- idempotent for a single chunk; the scope's duration / n is then free of any per-scope event error
-      static const int repeat = [] { const char* e = getenv("VITTF_SIM_REPEAT"); return e && atoi(e) > 1 ? atoi(e) : 1; }();
+      vittf_note_kernel(VITTF_KERNEL_SIMILARITY, split ? "sim_accumulate_split" : "sim_accumulate");
       ProfScope ps(VITTF_KERNEL_SIMILARITY, st);
-      for (int r = 0; r < repeat; ++r) {
-        if (mode == 1) SIM_LAUNCH(true, 0, true)
-        else if (mode == 0) SIM_LAUNCH(false, 0, true)
-        else if (half) SIM_LAUNCH(false, 1, true)
-        else SIM_LAUNCH(false, 1, false)
-      }
+      if (mode == 1) SIM_LAUNCH(true, 0, true)
+      else if (mode == 0) SIM_LAUNCH(false, 0, true)
+      else if (half) SIM_LAUNCH(false, 1, true)
+      else SIM_LAUNCH(false, 1, false)
     }
 #undef SIM_LAUNCH
     a0 += n;

@@ -160,6 +160,9 @@ struct ProfScope {
   ~ProfScope() { if (tok) vittf_prof_end(tok, st); }
 };
 
+// which kernel a dispatcher launched for a profiler class (bench.py asks instead of re-deriving the dispatch rules)
+void vittf_note_kernel(int cls, const char* name);
+
 static inline int vittf_check_launch() {
   return hipGetLastError() == hipSuccess ? VITTF_OK : VITTF_ERR_LAUNCH;
 }

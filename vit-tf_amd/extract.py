@@ -21,8 +21,22 @@ AXIS_DIMS = {'z': (2, (0, 1)), 'y': (1, (0, 2)), 'x': (0, (1, 2))}
 # Slices per vittf_vit_k_features call.  Slices are independent and results do not depend on the batching (tested: 31 / 32 /
 # 256 give the same bits); larger batches amortise every launch's partial last round of workgroups (the 32 CLS rows of a
 # 32-slice batch cost the whole-row GEMMs a third round): 512^3 workload 1828 / 1852 / 1870 / 1879 / 1902 / 1906 slices/s at
-# batch 32 / 31 / 64 / 128 / 256 / 512 on one box.  256 slices = 5.6 GB of workspace (of 288 GB).
+# batch 32 / 31 / 64 / 128 / 256 / 512 on one box.  256 slices of N = 4097 tokens at D = 384 = 5.6 GB of workspace (of 288 GB).
 DEFAULT_ENGINE_BATCH = 256
+
+
+def engine_batch_for(tokens, embed_dim, requested=None):
+    """Slices per engine call.  The default keeps the workspace at what 256 slices of N = 4097, D = 384 take (~5.6 GB per
+    stream lane) whatever the token count and width: 256 * 4097 * 384 / (tokens * D), clamped to 1 .. 256 -- the fos-128
+    preset (N = 16385) then runs 64 slices per call, ViT-B/8 128.  `requested` (infer.py --batch-size > 1, bench.py
+    --engine-batch) or VITTF_ENGINE_BATCH lower or raise it; results never depend on it."""
+    env = __import__('os').environ.get('VITTF_ENGINE_BATCH')
+    if env:
+        return max(1, int(env))
+    if requested:
+        return max(1, int(requested))
+    budget = DEFAULT_ENGINE_BATCH * 4097 * 384
+    return max(1, min(DEFAULT_ENGINE_BATCH, budget // (int(tokens) * int(embed_dim))))
 # Batches of slices are independent, so consecutive batches can go round-robin onto several HIP streams (each with
 # its own workspace): the VALU/MFMA-bound attention of one batch then overlaps the HBM-bound LayerNorm / GEMM
 # epilogues of another and covers the under-filled last wave of workgroups of every launch.  Measured +5.9 % slices/s
@@ -92,9 +106,10 @@ def _axis_geometry(shape, im_sizes, axis, patch):
     return sl, a, b, shape[sl], im_sizes[a] // patch, im_sizes[b] // patch
 
 
-def k_slices(model, dvol, axis, im_sizes, s0, s1, engine_batch=DEFAULT_ENGINE_BATCH, part=1, out=None):
+def k_slices(model, dvol, axis, im_sizes, s0, s1, engine_batch=None, part=1, out=None):
     """Token-major fp16 features of slices [s0, s1) of one axis: tensor [s1-s0, f0*f1, D] on the device."""
     _, _, _, _, f0, f1 = _axis_geometry(dvol.shape, im_sizes, axis, model.patch_size)
+    engine_batch = engine_batch_for(f0 * f1 + 1, model.embed_dim, engine_batch)
     n = s1 - s0
     per = f0 * f1 * model.embed_dim
     if out is None:
@@ -171,7 +186,7 @@ def _slab_shape_strides(axis, d, n, chunk):
     return (d, *dims), (dims[0] * dims[1] * dims[2], st[sl], st[a], st[b])
 
 
-def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=DEFAULT_ENGINE_BATCH, part=1, group=None,
+def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=None, part=1, group=None,
                   ops=_HIP_OPS, pending=None):
     """Pooled (n_out windows along the slice dim) features of one axis, gathered over the process group.
 
@@ -215,13 +230,16 @@ def _all_gather_slabs(gathered, slab, group, defer=False):
     2-ranks-on-1-GPU rehearsal) gets the list form, staged through the host when the backend cannot take device tensors."""
     world = gathered.shape[0]
     flat = gathered.view(world, -1)
-    mine = slab.reshape(-1).clone()
     backend = torch.distributed.get_backend(group)
     if backend == 'nccl':
+        # in place: this rank's slab already sits at flat[rank], which is exactly where an all-gather writes the rank's own
+        # contribution (send buffer = receive buffer + rank * count, RCCL's in-place form): no staging copy
+        mine = flat[torch.distributed.get_rank(group)]
         if defer:
             return torch.distributed.all_gather_into_tensor(flat.view(-1), mine, group=group, async_op=True), mine
         torch.distributed.all_gather_into_tensor(flat.view(-1), mine, group=group)
         return None
+    mine = slab.reshape(-1).clone()       # gloo: the output list must not alias the input
     if flat.is_cuda:
         host = [torch.empty(flat.shape[1], dtype=flat.dtype) for _ in range(world)]
         torch.distributed.all_gather(host, mine.cpu(), group=group)
@@ -244,7 +262,7 @@ def assemble_axis(gathered, axis, n_total):
     return full.narrow(1 + sl, 0, n_total).contiguous()
 
 
-def feature_volume(vol, model, feature_output_size=64, slice_along='all', engine_batch=DEFAULT_ENGINE_BATCH,
+def feature_volume(vol, model, feature_output_size=64, slice_along='all', engine_batch=None,
                    part=1, group=None, dvol=None, ops=_HIP_OPS):
     """infer.py:314-333 on the GPU(s).  Returns the fp16 feature tensor on the device:
     'all' -> (D, W', H', D') = fp16(fp16(z + y) + x) of the pooled axes; 'x'|'y'|'z' -> un-pooled single axis."""
@@ -270,7 +288,7 @@ def feature_volume(vol, model, feature_output_size=64, slice_along='all', engine
     return out.squeeze()        # the reference's running sum drops singleton dims (infer.py:332 v.squeeze())
 
 
-def pooled_axis(vol, model, axis, im_sizes, out_size, engine_batch=DEFAULT_ENGINE_BATCH, part=1, group=None, dvol=None,
+def pooled_axis(vol, model, axis, im_sizes, out_size, engine_batch=None, part=1, group=None, dvol=None,
                 ops=_HIP_OPS):
     """compute_qkv(..., pool_fn=AdaptiveAvgPool3d(out_size)) for one axis: (D, *out_size) fp16 on the device."""
     if dvol is None:

@@ -40,8 +40,19 @@ def arch_of(arch):
     return int(dim), int(depth), int(heads), int(patch)
 
 
-def synthetic_state_dict(arch='vits8', seed=0, stored_grid=28):
+# "massive activation" channels of the outlier variant below (trained ViTs carry a handful of residual-stream channels two
+# orders of magnitude above the rest; Gaussian unit-gain weights have none)
+OUTLIER_CHANNELS = (7, 100, 191, 250, 333, 380)
+
+
+def synthetic_state_dict(arch='vits8', seed=0, stored_grid=28, outliers=False):
     """Seeded random weights with the DINO key layout.
+
+    outliers=True: the same weights with six massive channels planted -- x50 rows in two blocks' mlp.fc2 and one block's
+    attn.proj (the residual stream then carries them to the end), x50 entries in several norm weights (16-bit LayerNorm
+    output in the hundreds), and in one block a q / k pair of one head that both read the same massive direction, so that
+    its attention logits spread over more than +-60: what the parity tests on benign weights never drive through the 16-bit
+    operand path (LN -> h, GELU -> hidden, the lazy-maximum attention kernel's overflow branch).
 
     Not an initialisation for training: the scales are chosen so that a forward pass looks like a trained
     ViT numerically (unit-gain linears, attention logits with a std of a few units so the softmax is
@@ -76,6 +87,25 @@ def synthetic_state_dict(arch='vits8', seed=0, stored_grid=28):
         sd[p + 'mlp.fc1.bias'] = rnd(4 * dim, std=0.1)
         sd[p + 'mlp.fc2.weight'] = rnd(dim, 4 * dim, std=1.0 / math.sqrt(4 * dim))
         sd[p + 'mlp.fc2.bias'] = rnd(dim, std=0.1)
+    if outliers:
+        c = [ch % dim for ch in OUTLIER_CHANNELS]
+        for blk in (1, depth // 2):
+            sd[f'blocks.{blk}.mlp.fc2.weight'][c[0]] *= 50.0
+            sd[f'blocks.{blk}.mlp.fc2.weight'][c[1]] *= 50.0
+        sd[f'blocks.{2 % depth}.attn.proj.weight'][c[2]] *= 50.0
+        for blk in range(depth):
+            sd[f'blocks.{blk}.norm1.weight'][c[3]] *= 50.0 if blk % 3 == 0 else 1.0
+            sd[f'blocks.{blk}.norm2.weight'][c[4]] *= 50.0 if blk % 3 == 1 else 1.0
+        # one head whose q and k both follow the (massive) channel c[0] of the normalised input: logits = 64 a^2 h_q h_k / 8
+        # (all of one sign there: logits up to ~140 but a spread of only ~10 inside a row), and one head that follows a
+        # channel whose sign changes with the token's position (its position embedding is x 20): logits of both signs
+        # inside one row, i.e. keys far above the first key tile's maximum late in the sequence
+        sd['pos_embed'][0, :, c[5]] *= 20.0
+        blk = min(depth - 2, 6)
+        wq = sd[f'blocks.{blk}.attn.qkv.weight']
+        for head, ch, a in ((1 % heads, c[0], 0.5), (2 % heads, c[5], 0.6)):
+            wq[head * 64:(head + 1) * 64, ch] += a
+            wq[dim + head * 64:dim + (head + 1) * 64, ch] += a
     return sd
 
 
