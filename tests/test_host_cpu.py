@@ -184,21 +184,27 @@ def test_bench_flop_formula_matches_survey_figures():
 
 
 def test_bench_pmc_traffic_only_for_the_measured_kernel(tmp_path, monkeypatch):
-    """A committed PMC pass prices `roofline.traffic` only for the very kernel source, kernel and shape it was taken on."""
+    """A committed PMC pass prices `roofline.traffic` only for the very code object (kernel source, shared headers, Makefile
+    flags), kernel, shape and batch it was taken on."""
     import json
     import bench
     (tmp_path / 'profiles').mkdir()
     src = tmp_path / 'vit-tf_amd' / 'csrc'
     src.mkdir(parents=True)
-    (src / 'k.hip').write_text('kernel v1')
+    for name in bench.KERNEL_SOURCES['attention']:
+        (src / name).write_text(f'{name} v1')
     monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
-    rec = {'batch': 32, 'tokens': 4097, 'hbm_bytes_per_launch': 1000, 'source_sha1': bench.kernel_source_hash('k.hip')}
+    rec = {'batch': 256, 'tokens': 4097, 'hbm_bytes_per_launch': 1000, 'source_sha1': bench.kernel_source_hash('attention')}
     (tmp_path / 'profiles' / 'pmc_attention.json').write_text(json.dumps(rec))
-    assert bench.pmc_traffic('attention', 256, 'k.hip', tokens=4097) == 8000            # scales with the slices per launch
-    assert bench.pmc_traffic('attention', 256, 'k.hip', tokens=16385) is None           # another shape
-    assert bench.pmc_traffic('similarity', 16, 'k.hip') is None                          # no pass on file
-    (src / 'k.hip').write_text('kernel v2')
-    assert bench.pmc_traffic('attention', 256, 'k.hip', tokens=4097) is None            # the kernel changed since the pass
+    assert bench.pmc_traffic('attention', 256, tokens=4097) == 1000
+    assert bench.pmc_traffic('attention', 32, tokens=4097) is None              # a pass at another batch is not this launch
+    assert bench.pmc_traffic('attention', 256, tokens=16385) is None            # another shape
+    assert bench.pmc_traffic('similarity', 16) is None                          # no pass on file
+    for changed in ('Makefile', 'attn_common.h', bench.KERNEL_SOURCES['attention'][0]):
+        (src / changed).write_text('v2')
+        assert bench.pmc_traffic('attention', 256, tokens=4097) is None        # the code object changed since the pass
+        (src / changed).write_text(f'{changed} v1')
+        assert bench.pmc_traffic('attention', 256, tokens=4097) == 1000
 
 
 def test_engine_batch_follows_a_workspace_budget(monkeypatch):
