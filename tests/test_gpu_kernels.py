@@ -705,6 +705,56 @@ def test_similarity_mfma_path_shapes(gpu, monkeypatch, grid, counts, min_a):
             assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, (k, name, int(d.max()), float((d > 0).float().mean()))
 
 
+@pytest.mark.parametrize('grid,counts', [((24, 20, 18), (70, 3, 33)),          # 8640 voxels: a partial last 512-voxel workgroup
+                                         ((16, 16, 16), (1,) * 5 + (40,)),       # 8 workgroups, one-annotation classes
+                                         ((64, 8, 8), (1024, 1024))])
+def test_similarity_mfma_two_voxel_blocks_per_wave(gpu, monkeypatch, grid, counts):
+    """sim_mfma_kernel with two 32-voxel blocks per wave (512-voxel workgroups: the shape the 5 x 1024-query preset runs at
+    size) forced on small volumes: every voxel goes through the same MFMA sequence as with one block per wave, so the maps
+    are the same BYTES; and both match the oracle."""
+    g = gen(sum(grid) + len(counts) + 5)
+    feat = torch.nn.functional.normalize(torch.randn(384, *grid, generator=g), dim=0)
+    feat = torch.nn.functional.normalize((feat + 0.7 * feat[:, 2:3, 3:4, 4:5]).half().float(), dim=0).half()
+    shape = tuple(2 * s for s in grid)
+    ann = {f'c{i}': torch.stack([torch.randint(0, s, (n,), generator=g) for s in shape], 1) for i, n in enumerate(counts)}
+    monkeypatch.setenv('VITTF_SIM_MFMA_MIN', '2')
+    monkeypatch.setenv('VITTF_SIM_MFMA_VB', '2')
+    two = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann)
+    assert _lib.kernel_name('similarity') == 'sim_mfma_kernel<2 voxel blocks>'
+    monkeypatch.setenv('VITTF_SIM_MFMA_VB', '1')
+    one = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann)
+    assert _lib.kernel_name('similarity') == 'sim_mfma_kernel'
+    ref = osim.similarity_maps(shape, feat.float(), ann)
+    for k in ann:
+        assert torch.equal(two[k], one[k]), k
+        d = (two[k].int() - ref[k].int()).abs()
+        d = torch.minimum(d, 256 - d)
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, (k, int(d.max()), float((d > 0).float().mean()))
+
+
+@pytest.mark.parametrize('grid,counts', [((16, 16, 16), (70, 3, 33)), ((24, 20, 18), (1024, 200)), ((16, 16, 16), (2,) * 40)])
+def test_similarity_mfma_768_features(gpu, monkeypatch, grid, counts):
+    """ViT-B/8 feature volumes (F = 768) on the matrix-core similarity kernel: a 32-query chunk is two 384-feature units, the
+    accumulators run over both -- against the oracle and against the VALU kernels (which took every F != 384 before)."""
+    g = gen(sum(grid) + len(counts) + 768)
+    feat = torch.nn.functional.normalize(torch.randn(768, *grid, generator=g), dim=0)
+    feat = torch.nn.functional.normalize((feat + 0.7 * feat[:, 2:3, 3:4, 4:5]).half().float(), dim=0).half()
+    shape = tuple(2 * s for s in grid)
+    ann = {f'c{i}': torch.stack([torch.randint(0, s, (n,), generator=g) for s in shape], 1) for i, n in enumerate(counts)}
+    got = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann)
+    assert _lib.kernel_name('similarity') == 'sim_mfma_kernel<F 768>'
+    monkeypatch.setenv('VITTF_SIM_MFMA', '0')
+    monkeypatch.setenv('VITTF_SIM_MFMA_MIN', '1000000')
+    valu = vt.compute_similarities(np.zeros(shape, np.float32), feat, ann)
+    assert _lib.kernel_name('similarity').startswith('sim_accumulate')
+    ref = osim.similarity_maps(shape, feat.float(), ann)
+    for k in ann:
+        for name, other in (('oracle', ref[k]), ('VALU kernels', valu[k])):
+            d = (got[k].int() - other.int()).abs()
+            d = torch.minimum(d, 256 - d)
+            assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.01, (k, name, int(d.max()), float((d > 0).float().mean()))
+
+
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('rows,n,epi', [(1, 384, 'bias'), (77, 1152, 'bias'), (4097, 1536, 'gelu'), (19205, 1152, 'bias')])
 def test_ln_gemm_fused(gpu, dt, rows, n, epi):

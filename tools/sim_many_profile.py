@@ -21,6 +21,31 @@ def t(fn, reps=10):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 
+def kernel_ms(fv, reps=10):
+    """events around the accumulation kernel alone (the library's profiler class 'similarity')"""
+    vt.compute_similarities(vol, fv, ann, keep_on_device=True)
+    vt._lib.profiler_enable(True, classes=['similarity'])
+    for _ in range(reps):
+        vt.compute_similarities(vol, fv, ann, keep_on_device=True)
+    torch.cuda.synchronize()
+    ms, n = vt._lib.profiler_collect()['similarity']
+    vt._lib.profiler_enable(False)
+    return ms / max(1, n), vt._lib.kernel_name('similarity')
+
+
+# one / two voxel blocks per wave, interleaved in this process (5 x 1024 queries, 64^3 x 384), and the 768-feature volume
+feat_n = torch.nn.functional.normalize(feat.float(), dim=0).half()
+for rnd in range(3):
+    for vb in ('1', '2'):
+        os.environ['VITTF_SIM_MFMA_VB'] = vb
+        ms, name = kernel_ms(feat_n)
+        print(f'round {rnd}: accumulation kernel {name:34s} {ms:.3f} ms  ({2 * 2 * 5120 * 262144 * 384 / ms / 1e9:.0f} TFLOP/s incl. the hi + lo split)')
+os.environ.pop('VITTF_SIM_MFMA_VB')
+feat768 = torch.nn.functional.normalize(torch.randn(768, 64, 64, 64, generator=g), dim=0).half().to(dev)
+ms, name = kernel_ms(feat768)
+print(f'768 features: accumulation kernel {name:34s} {ms:.3f} ms  ({2 * 2 * 5120 * 262144 * 768 / ms / 1e9:.0f} TFLOP/s incl. the split)')
+del feat768
+
 # the same call on volumes whose (query, voxel) similarities look like a segmentation task's: unit-norm features around 5
 # cluster centres (a query passes the 0.25 threshold on its own cluster's voxels only), and unit-norm noise (never)
 centres = torch.nn.functional.normalize(torch.randn(5, 384, generator=g), dim=1)

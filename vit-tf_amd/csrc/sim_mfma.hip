@@ -1,4 +1,4 @@
-// Per-class similarity maps on the matrix cores (F = 384): the interactive few-query case and BASELINE configs[4].
+// Per-class similarity maps on the matrix cores (F = 384 and 768): the interactive few-query case and BASELINE configs[4].
 //
 // Same arithmetic as sim_accumulate (similarity.hip; predict_ntf.py:65, 71-72): for every voxel and class,
 // mean over the class's annotations of where(q . x >= 0.25, q . x, 0) ** 2.5.  The VALU kernel spends 16 FMAs per
@@ -17,7 +17,12 @@
 //     a linear LDS-DMA copy into a 2-deep ring;
 //   * per chunk and wave 48 x v_mfma_f32_32x32x16_f16 (rows = queries, columns = voxels), then the activation and
 //     the in-lane sum over the 16 query rows a lane holds; one barrier per chunk;
-//   * the class table travels as a kernel argument (up to 32 classes; more: device tables filled by copies).
+//   * the class table travels as a kernel argument (up to 32 classes; more: device tables filled by copies);
+//   * round 3: the streaming unit stays one 48 KB image of [32 queries][384 features] (hi + lo), but a wave's 192 operand
+//     registers hold either TWO 32-voxel blocks of 384 features (workgroup = 512 voxels: every query fragment read from LDS
+//     feeds four MFMAs instead of two, and every staged chunk serves twice the voxels -- the 5 x 1024-query preset was bound
+//     by exactly these two streams) or ONE block of 768 features (ViT-B/8 volumes: a 32-query chunk is two units, the
+//     accumulators run over both before the activation).
 #include "vittf_common.h"
 
 #include <stdlib.h>
@@ -36,10 +41,12 @@ struct SmClasses { int n; int start[SM_MAXC + 1]; };   // n = 0: the tables are 
 // padded query p (class-major, each class padded to a multiple of 32) <- source row (-1: zero row): from the class table
 // in the argument, or from src_row[p] when there are more than SM_MAXC classes
 __global__ __launch_bounds__(256) void sim_mfma_prep(const float* __restrict__ qf, SmClasses cl, const int* __restrict__ src_row,
-                                                     int padded, char* __restrict__ img) {
-  const int e = blockIdx.x * 256 + threadIdx.x;          // one 16-byte chunk of one padded row
-  if (e >= padded * 48) return;
-  const int p = e / 48, c = e - 48 * p;
+                                                     int padded, char* __restrict__ img, int ku) {
+  const int e = blockIdx.x * 256 + threadIdx.x;          // one 16-byte chunk of one padded row (48 ku chunks per row)
+  if (e >= padded * 48 * ku) return;
+  const int p = e / (48 * ku), cw = e - 48 * ku * p;     // cw: chunk inside the whole row
+  const int u = cw / 48, c = cw - 48 * u;                // unit (384-feature half of a 768-wide row), chunk inside the unit
+  const int F = SM_F * ku;
   int src = -1;
   if (cl.n > 0) {
     int p0 = 0;
@@ -55,55 +62,62 @@ __global__ __launch_bounds__(256) void sim_mfma_prep(const float* __restrict__ q
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float q0 = 0.f, q1 = 0.f;
-    if (src >= 0) { q0 = qf[(int64_t)src * SM_F + 8 * c + 2 * j]; q1 = qf[(int64_t)src * SM_F + 8 * c + 2 * j + 1]; }
+    if (src >= 0) { q0 = qf[(int64_t)src * F + 8 * cw + 2 * j]; q1 = qf[(int64_t)src * F + 8 * cw + 2 * j + 1]; }
     const unsigned short h0 = f32_to_f16bits(q0), h1 = f32_to_f16bits(q1);
     const unsigned short l0 = f32_to_f16bits(q0 - f16bits_to_f32(h0)), l1 = f32_to_f16bits(q1 - f16bits_to_f32(h1));
     hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
     lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
   }
-  char* dst = img + (int64_t)(p >> 5) * SM_CHUNK + (c >> 3) * 4096 + tile_off(p & 31, c & 7);
+  char* dst = img + ((int64_t)(p >> 5) * ku + u) * SM_CHUNK + (c >> 3) * 4096 + tile_off(p & 31, c & 7);
   *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
   *reinterpret_cast<uint4*>(dst + SM_PART) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
 __device__ __forceinline__ float sm_thresh_pow(float s) { return s >= 0.25f ? s * s * sqrt_cr_normal(s) : 0.f; }   // (vittf_common.h: same bits as sqrtf, a third of its instructions)
 
-constexpr int SM_ROWS_PART = 96;                    // feature rows per staged part: 96 x 512 B = 48 KB = one half of the ring
-static_assert(SM_ROWS_PART * 512 == SM_CHUNK && SM_F % SM_ROWS_PART == 0, "a part of the volume tile fills one ring half");
-
-template <bool DMA>
+// KU = 384-feature units per query row (1: F = 384, 2: F = 768); VB = 32-voxel blocks per wave (workgroup = 256 VB voxels).
+// KU x VB <= 2: the voxel operands fill 96 KU VB registers.
+template <bool DMA, int KU, int VB>
 __global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned short* __restrict__ feat, int64_t nvox,
                                                               const char* __restrict__ qimg, SmClasses cl,
                                                               const int* __restrict__ chunk_start,
                                                               const float* __restrict__ counts, int classes, int total,
                                                               const float* __restrict__ vnorm, float* __restrict__ sim,
                                                               unsigned* __restrict__ maxbits) {
+  static_assert(KU * VB <= 2, "register budget");
+  constexpr int F = SM_F * KU, KST = SM_KS * KU;             // features, 16-wide k steps per voxel
+  constexpr int ROWS_PART = 96 / VB;                         // feature rows per staged part and 256-voxel half: 48 KB per part
+  constexpr int PARTS = F / ROWS_PART, KS_PART = ROWS_PART / 16;
   __shared__ __attribute__((aligned(16))) char ring[2 * SM_CHUNK];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int64_t v0 = (int64_t)blockIdx.x * SM_VOX;
-  const int64_t v = v0 + wave * 32 + l31;
-  const bool valid = v < nvox;
+  const int64_t v0 = (int64_t)blockIdx.x * (SM_VOX * VB);
+  int64_t v[VB];
+  bool valid[VB];
+#pragma unroll
+  for (int b = 0; b < VB; ++b) { v[b] = v0 + b * SM_VOX + wave * 32 + l31; valid[b] = v[b] < nvox; }
   const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(ring);
 
-  // the wave's 32 voxels x 384 features as B operands: xf[s] = features 16 s + 8 h .. + 7 of voxel v
-  s16x8_t xf[SM_KS];
+  // the wave's VB x 32 voxels x F features as B operands: xf[b][s] = features 16 s + 8 h .. + 7 of voxel v[b]
+  s16x8_t xf[VB][KST];
   if constexpr (DMA) {
-    // Part p = feature rows 96 p .. 96 p + 95 of the workgroup's 256 voxels, 512 B per row, into ring half p & 1.  One
-    // DMA instruction of a wave = two rows (lanes 0-31 / 32-63): LDS position (lane & 31) of row r holds the row's 16-byte
-    // chunk (lane & 31) ^ 4 (r & 3) -- swizzled on the source side, the destination of an LDS-DMA is lane-linear -- so
-    // that the four rows of a transposing read sit on four different 64-byte bank groups.  A chunk beyond the end of
-    // the row (partial last workgroup) reads the row's last chunk instead: its voxels are never stored.
+    // Part p = feature rows ROWS_PART p .. of the workgroup's VB halves of 256 voxels, 512 B per row and half, the halves
+    // one behind the other in ring half p & 1.  One DMA instruction of a wave = two rows (lanes 0-31 / 32-63): LDS position
+    // (lane & 31) of row r holds the row's 16-byte chunk (lane & 31) ^ 4 (r & 3) -- swizzled on the source side, the
+    // destination of an LDS-DMA is lane-linear -- so that the four rows of a transposing read sit on four different 64-byte
+    // bank groups.  A chunk beyond the end of the row (partial last workgroup) reads the row's last chunk instead: its
+    // voxels are never stored.
     const int64_t last_chunk = nvox - 8;
 #define SM_STAGE_ROWS(P)                                                                                   \
     {                                                                                                      \
       _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                      \
-        const int r_ = 2 * (wave * 6 + i) + h;                                                             \
-        int64_t vs_ = v0 + 8 * (l31 ^ (4 * (r_ & 3)));                                                     \
+        const int j_ = wave * 6 + i;                          /* 1 KB piece of the 48 KB part */           \
+        const int hf_ = j_ / (ROWS_PART / 2), r_ = 2 * (j_ % (ROWS_PART / 2)) + h;                         \
+        int64_t vs_ = v0 + hf_ * SM_VOX + 8 * (l31 ^ (4 * (r_ & 3)));                                      \
         vs_ = vs_ < last_chunk ? vs_ : last_chunk;                                                         \
-        lds_dma16_flat(feat + (int64_t)((P) * SM_ROWS_PART + r_) * nvox + vs_,                             \
-                       ring_lds + ((P) & 1) * SM_CHUNK + (wave * 6 + i) * 1024);                           \
+        lds_dma16_flat(feat + (int64_t)((P) * ROWS_PART + r_) * nvox + vs_,                                \
+                       ring_lds + ((P) & 1) * SM_CHUNK + j_ * 1024);                                       \
       }                                                                                                    \
     }
     // transposing read: 16-lane group g = lane >> 4 covers voxels 16 (g & 1) .. + 15 of the wave's 32 and k-group g >> 1;
@@ -114,37 +128,46 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned sho
     SM_STAGE_ROWS(0)
     SM_STAGE_ROWS(1)
 #pragma unroll
-    for (int p = 0; p < SM_F / SM_ROWS_PART; ++p) {
-      if (p + 1 < SM_F / SM_ROWS_PART) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // part p landed (6 pieces of p + 1 may be in flight)
+    for (int p = 0; p < PARTS; ++p) {
+      if (p + 1 < PARTS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // part p landed (6 pieces of p + 1 may be in flight)
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
-      const char* buf = ring + (p & 1) * SM_CHUNK + tr_off;
 #pragma unroll
-      for (int s = 0; s < SM_ROWS_PART / 16; ++s) {
-        const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s) * 512));
-        const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s + 4) * 512));
-        s16x8_t t;
-        t[0] = a[0]; t[1] = a[1]; t[2] = a[2]; t[3] = a[3]; t[4] = b[0]; t[5] = b[1]; t[6] = b[2]; t[7] = b[3];
-        xf[(SM_ROWS_PART / 16) * p + s] = t;
+      for (int b = 0; b < VB; ++b) {
+        const char* buf = ring + (p & 1) * SM_CHUNK + b * (ROWS_PART * 512) + tr_off;
+#pragma unroll
+        for (int s = 0; s < KS_PART; ++s) {
+          const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s) * 512));
+          const s16x4_t c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s + 4) * 512));
+          s16x8_t t;
+          t[0] = a[0]; t[1] = a[1]; t[2] = a[2]; t[3] = a[3]; t[4] = c[0]; t[5] = c[1]; t[6] = c[2]; t[7] = c[3];
+          xf[b][KS_PART * p + s] = t;
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                      // everybody has read ring half p & 1
-      if (p + 2 < SM_F / SM_ROWS_PART) SM_STAGE_ROWS(p + 2)
+      if (p + 2 < PARTS) SM_STAGE_ROWS(p + 2)
     }
 #undef SM_STAGE_ROWS
   } else {
 #pragma unroll
-    for (int s = 0; s < SM_KS; ++s) {
-      s16x8_t t;
+    for (int b = 0; b < VB; ++b)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = valid ? (short)feat[(int64_t)(16 * s + 8 * h + j) * nvox + v] : (short)0;
-      xf[s] = t;
-    }
+      for (int s = 0; s < KST; ++s) {
+        s16x8_t t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = valid[b] ? (short)feat[(int64_t)(16 * s + 8 * h + j) * nvox + v[b]] : (short)0;
+        xf[b][s] = t;
+      }
   }
-  const float nv = (vnorm && valid) ? vnorm[v] : 1.f;
+  float nv[VB];
+#pragma unroll
+  for (int b = 0; b < VB; ++b) nv[b] = (vnorm && valid[b]) ? vnorm[v[b]] : 1.f;
 
-  const i32x4_t rsrc = lds_dma_rsrc(qimg, (unsigned)((int64_t)total * SM_CHUNK < 0x7fffffff ? (int64_t)total * SM_CHUNK : 0x7fffffff));
+  // the query stream: units of 48 KB ([32 queries][384 features], hi | lo), KU per 32-query chunk
+  const int units = total * KU;
+  const i32x4_t rsrc = lds_dma_rsrc(qimg, (unsigned)((int64_t)units * SM_CHUNK < 0x7fffffff ? (int64_t)units * SM_CHUNK : 0x7fffffff));
   const int voff = lane * 16;
-  // chunk g -> ring[g & 1]: 48 pieces of 1 KB, 6 per wave
+  // unit g -> ring[g & 1]: 48 pieces of 1 KB, 6 per wave
 #define SM_STAGE(G)                                                                                     \
   {                                                                                                     \
     const unsigned dst_ = ring_lds + ((G) & 1) * SM_CHUNK + wave * 6144;                                \
@@ -152,43 +175,60 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_kernel(const unsigned sho
     _Pragma("unroll") for (int i = 0; i < 6; ++i) lds_dma16(rsrc, dst_ + i * 1024, voff, src_ + i * 1024); \
   }
   const int aoff0 = tile_off(l31, h);
-  if (total > 0) SM_STAGE(0)
-  int g = 0;
+  if (units > 0) SM_STAGE(0)
+  int g = 0;                              // chunk
   int g_end = 0;
   for (int c = 0; c < classes; ++c) {
-    float csum = 0.f;
+    float csum[VB];
+#pragma unroll
+    for (int b = 0; b < VB; ++b) csum[b] = 0.f;
     const int n_c = cl.n > 0 ? cl.start[c + 1] - cl.start[c] : 0;
     g_end = cl.n > 0 ? g_end + ((n_c + 31) >> 5) : chunk_start[c + 1];
     const float count = cl.n > 0 ? (float)n_c : counts[c];
     for (; g < g_end; ++g) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // chunk g landed; ring[(g + 1) & 1] is free
-      if (g + 1 < total) SM_STAGE(g + 1)
-      const char* buf = ring + (g & 1) * SM_CHUNK;
-      f32x16_t acc;
+      f32x16_t acc[VB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int b = 0; b < VB; ++b)
 #pragma unroll
-      for (int s = 0; s < SM_KS; ++s) {
-        const int off = (s >> 2) * 4096 + (aoff0 ^ (32 * (s & 3)));
-        const s16x8_t qh = *reinterpret_cast<const s16x8_t*>(buf + off);
-        const s16x8_t ql = *reinterpret_cast<const s16x8_t*>(buf + SM_PART + off);
-        acc = mfma32<VITTF_FP16>(qh, xf[s], acc);
-        acc = mfma32<VITTF_FP16>(ql, xf[s], acc);
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int gu = g * KU + u;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // unit gu landed; ring[(gu + 1) & 1] is free
+        if (gu + 1 < units) SM_STAGE(gu + 1)
+        const char* buf = ring + (gu & 1) * SM_CHUNK;
+#pragma unroll
+        for (int s = 0; s < SM_KS; ++s) {
+          const int off = (s >> 2) * 4096 + (aoff0 ^ (32 * (s & 3)));
+          const s16x8_t qh = *reinterpret_cast<const s16x8_t*>(buf + off);
+          const s16x8_t ql = *reinterpret_cast<const s16x8_t*>(buf + SM_PART + off);
+#pragma unroll
+          for (int b = 0; b < VB; ++b) acc[b] = mfma32<VITTF_FP16>(qh, xf[b][SM_KS * u + s], acc[b]);
+#pragma unroll
+          for (int b = 0; b < VB; ++b) acc[b] = mfma32<VITTF_FP16>(ql, xf[b][SM_KS * u + s], acc[b]);
+        }
       }
-      float part0 = 0.f, part1 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        part0 += sm_thresh_pow(vnorm ? acc[r] / nv : acc[r]);
-        part1 += sm_thresh_pow(vnorm ? acc[r + 1] / nv : acc[r + 1]);
+      for (int b = 0; b < VB; ++b) {
+        float part0 = 0.f, part1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          part0 += sm_thresh_pow(vnorm ? acc[b][r] / nv[b] : acc[b][r]);
+          part1 += sm_thresh_pow(vnorm ? acc[b][r + 1] / nv[b] : acc[b][r + 1]);
+        }
+        csum[b] += part0 + part1;
       }
-      csum += part0 + part1;
     }
     // the two lane halves hold the other 16 query rows of every chunk
-    const unsigned cb = __float_as_uint(csum);
-    const auto sw = __builtin_amdgcn_permlane32_swap(cb, cb, false, false);
-    const float mean = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) / count;
-    if (valid && h == 0) sim[(int64_t)c * nvox + v] = mean;
-    float m = valid ? mean : 0.f;
+    float m = 0.f;
+#pragma unroll
+    for (int b = 0; b < VB; ++b) {
+      const unsigned cb = __float_as_uint(csum[b]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(cb, cb, false, false);
+      const float mean = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) / count;
+      if (valid[b] && h == 0) sim[(int64_t)c * nvox + v[b]] = mean;
+      m = fmaxf(m, valid[b] ? mean : 0.f);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     if (lane == 0) atomic_max_nonneg(maxbits + c, m);
@@ -345,17 +385,23 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
 }  // namespace
 
 size_t vittf_sim_mfma_workspace_bytes(int32_t classes, int32_t annotations) {
-  // worst case: every class padded by 31 rows; + the row map, chunk table and class counts
+  // worst case: every class padded by 31 rows, 768-wide rows (two 48 KB units per chunk); + the row map, chunk table and
+  // class counts
   const size_t chunks = ((size_t)annotations + 31 * (size_t)classes + 31) / 32;
-  return chunks * SM_CHUNK + ((chunks * 32 * 4 + 255) & ~(size_t)255) + (((size_t)classes + 1) * 8 + 255 & ~(size_t)255) + 256;
+  return chunks * 2 * SM_CHUNK + ((chunks * 32 * 4 + 255) & ~(size_t)255) + (((size_t)classes + 1) * 8 + 255 & ~(size_t)255) + 256;
 }
 
 // does the matrix-core path take this query set?  (asked before the profiler scope is opened: an empty scope would count
 // as a launch of the class)
-bool vittf_sim_mfma_applies(int32_t f, int32_t classes, int32_t total_a, const void* ws, size_t ws_bytes) {
+static bool sm_rows_aligned(const void* feat, int64_t nvox) { return nvox % 8 == 0 && nvox >= 8 && ((uintptr_t)feat & 15) == 0; }
+
+bool vittf_sim_mfma_applies(int32_t f, int32_t classes, int32_t total_a, const void* ws, size_t ws_bytes, const void* feat,
+                            int64_t nvox) {
   const char* e = getenv("VITTF_SIM_MFMA_MIN");   // (read per call: the tests switch it)
   const int min_a = e ? atoi(e) : SM_MIN_A;
-  return f == SM_F && total_a >= min_a && ws && ws_bytes >= vittf_sim_mfma_workspace_bytes(classes, total_a);
+  // 768-wide rows need the whole-row LDS-DMA (16-byte aligned feature rows): their strided-load form has no registers left
+  if (!(f == SM_F || (f == 2 * SM_F && sm_rows_aligned(feat, nvox)))) return false;
+  return total_a >= min_a && ws && ws_bytes >= vittf_sim_mfma_workspace_bytes(classes, total_a);
 }
 
 // fp32 class maps [classes][nvox] + per-class maxima; returns 1 when this path does not apply
@@ -363,16 +409,17 @@ int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, con
                         int32_t classes, const float* voxel_norm, float* sim, unsigned* maxbits, void* ws, size_t ws_bytes,
                         hipStream_t st) {
   const int total_a = class_start_host[classes];
-  if (!vittf_sim_mfma_applies(f, classes, total_a, ws, ws_bytes)) return 1;
+  if (!vittf_sim_mfma_applies(f, classes, total_a, ws, ws_bytes, feat, nvox)) return 1;
   SmClasses cl;
   cl.n = classes <= SM_MAXC ? classes : 0;
   for (int c = 0; c <= SM_MAXC; ++c) cl.start[c] = c <= classes && cl.n ? class_start_host[c] : 0;
   size_t chunks = 0;
   for (int c = 0; c < classes; ++c) chunks += (size_t)(class_start_host[c + 1] - class_start_host[c] + 31) / 32;
   const int padded = (int)(chunks * 32);
+  const int ku = f / SM_F;
   char* w = (char*)ws;
   char* img = w;
-  int* src_d = (int*)(w + chunks * SM_CHUNK);
+  int* src_d = (int*)(w + chunks * ku * SM_CHUNK);
   int* chunk_d = (int*)((char*)src_d + (((size_t)padded * 4 + 255) & ~(size_t)255));
   float* counts_d = (float*)(chunk_d + classes + 1);
   std::vector<int> src_row, chunk_start;
@@ -393,27 +440,39 @@ int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, con
   }
   const unsigned blocks = (unsigned)((nvox + SM_VOX - 1) / SM_VOX);
   // whole-row LDS-DMA needs 16-byte aligned rows; other volumes take the strided loads
-  const bool dma = nvox % 8 == 0 && nvox >= 8 && ((uintptr_t)feat & 15) == 0;
+  const bool dma = sm_rows_aligned(feat, nvox);
   // CUs of the CURRENT device (one process per GPU: the rank's device, not device 0), asked once
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
   }();
-  if (dma && cl.n == 1 && chunks == 1) {   // the interactive query: one class, one chunk; the kernel prepares the queries itself
+  if (dma && ku == 1 && cl.n == 1 && chunks == 1) {   // the interactive query: one class, one chunk; the kernel prepares the queries itself
     vittf_note_kernel(VITTF_KERNEL_SIMILARITY, "sim_mfma_few_kernel");
     hipLaunchKernelGGL(sim_mfma_few_kernel, dim3(blocks < (unsigned)cus ? blocks : (unsigned)cus), dim3(SM_THREADS), 0, st, feat, nvox,
                        qf + (size_t)class_start_host[0] * SM_F, total_a, (int)blocks, voxel_norm, sim, maxbits);
     return vittf_check_launch();
   }
-  vittf_note_kernel(VITTF_KERNEL_SIMILARITY, "sim_mfma_kernel");
-  hipLaunchKernelGGL(sim_mfma_prep, dim3((padded * 48 + 255) / 256), dim3(256), 0, st, qf, cl, src_d, padded, img);
-  if (dma)
-    hipLaunchKernelGGL(sim_mfma_kernel<true>, dim3(blocks), dim3(SM_THREADS), 0, st, feat, nvox, img, cl, chunk_d, counts_d, classes,
-                       (int)chunks, voxel_norm, sim, maxbits);
-  else
-    hipLaunchKernelGGL(sim_mfma_kernel<false>, dim3(blocks), dim3(SM_THREADS), 0, st, feat, nvox, img, cl, chunk_d, counts_d, classes,
-                       (int)chunks, voxel_norm, sim, maxbits);
+  hipLaunchKernelGGL(sim_mfma_prep, dim3((padded * 48 * ku + 255) / 256), dim3(256), 0, st, qf, cl, src_d, padded, img, ku);
+  // two voxel blocks per wave (512-voxel workgroups) when that still fills the chip; VITTF_SIM_MFMA_VB=1 forces one (read per
+  // call: the tests run both)
+  const char* evb = getenv("VITTF_SIM_MFMA_VB");
+  const int vb = (ku == 2 || !dma) ? 1 : (evb ? (atoi(evb) == 1 ? 1 : 2) : ((nvox + 2 * SM_VOX - 1) / (2 * SM_VOX) >= cus ? 2 : 1));
+  const unsigned wgs = (unsigned)((nvox + (int64_t)SM_VOX * vb - 1) / ((int64_t)SM_VOX * vb));
+#define SM_LAUNCH(DMAV, KUV, VBV)                                                                                     \
+  hipLaunchKernelGGL((sim_mfma_kernel<DMAV, KUV, VBV>), dim3(wgs), dim3(SM_THREADS), 0, st, feat, nvox, img, cl, chunk_d, counts_d, \
+                     classes, (int)chunks, voxel_norm, sim, maxbits)
+  if (ku == 2) {
+    vittf_note_kernel(VITTF_KERNEL_SIMILARITY, "sim_mfma_kernel<F 768>");
+    SM_LAUNCH(true, 2, 1);
+  } else if (vb == 2) {
+    vittf_note_kernel(VITTF_KERNEL_SIMILARITY, "sim_mfma_kernel<2 voxel blocks>");
+    SM_LAUNCH(true, 1, 2);
+  } else {
+    vittf_note_kernel(VITTF_KERNEL_SIMILARITY, "sim_mfma_kernel");
+    if (dma) SM_LAUNCH(true, 1, 1); else SM_LAUNCH(false, 1, 1);
+  }
+#undef SM_LAUNCH
   if (!cl.n && hipStreamSynchronize(st) != hipSuccess) return VITTF_ERR_LAUNCH;   // the host vectors above must outlive the copies
   return vittf_check_launch();
 }

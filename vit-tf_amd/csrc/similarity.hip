@@ -446,7 +446,8 @@ extern "C" int vittf_voxel_norm(const uint16_t* feat, int32_t f, int64_t nvox, f
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t vittf_sim_mfma_workspace_bytes(int32_t classes, int32_t annotations);                      // sim_mfma.hip
-bool vittf_sim_mfma_applies(int32_t f, int32_t classes, int32_t total_a, const void* ws, size_t ws_bytes);
+bool vittf_sim_mfma_applies(int32_t f, int32_t classes, int32_t total_a, const void* ws, size_t ws_bytes, const void* feat,
+                            int64_t nvox);
 int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, const float* qf, const int32_t* class_start_host,
                         int32_t classes, const float* voxel_norm, float* sim, unsigned* maxbits, void* ws, size_t ws_bytes,
                         hipStream_t st);                                                         // 1 = not applicable
@@ -487,9 +488,9 @@ int accumulate_class_maps(const void* feat, bool half, int32_t f, int64_t nvox, 
   if (hipMemsetAsync(maxbits, 0, (size_t)classes * 4, st) != hipSuccess) return VITTF_ERR_LAUNCH;
 
   const int total_a = class_start_host[classes];
-  if (mode == 0 && half && mfma_ws_bytes) {   // many annotations, F = 384: the volume is read once (sim_mfma.hip)
+  if (mode == 0 && half && mfma_ws_bytes) {   // many annotations, F = 384 / 768: the volume is read once (sim_mfma.hip)
     static const bool use_mfma = [] { const char* e = getenv("VITTF_SIM_MFMA"); return !e || atoi(e) != 0; }();
-    if (use_mfma && vittf_sim_mfma_applies(f, classes, total_a, mfma_ws, mfma_ws_bytes)) {   // (asked first: an empty scope would count as a launch)
+    if (use_mfma && vittf_sim_mfma_applies(f, classes, total_a, mfma_ws, mfma_ws_bytes, feat, nvox)) {   // (asked first: an empty scope would count as a launch)
       ProfScope ps(VITTF_KERNEL_SIMILARITY, st);
       const int rc = vittf_sim_mfma_maps((const unsigned short*)feat, f, nvox, qf, class_start_host, classes, voxel_norm, sim,
                                          maxbits, mfma_ws, mfma_ws_bytes, st);

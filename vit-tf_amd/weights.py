@@ -98,12 +98,12 @@ def synthetic_state_dict(arch='vits8', seed=0, stored_grid=28, outliers=False):
             sd[f'blocks.{blk}.norm2.weight'][c[4]] *= 50.0 if blk % 3 == 1 else 1.0
         # one head whose q and k both follow the (massive) channel c[0] of the normalised input: logits = 64 a^2 h_q h_k / 8
         # (all of one sign there: logits up to ~140 but a spread of only ~10 inside a row), and one head that follows a
-        # channel whose sign changes with the token's position (its position embedding is x 20): logits of both signs
+        # channel whose sign changes with the token's position (its position embedding is x 20): logits of both signs (+-60)
         # inside one row, i.e. keys far above the first key tile's maximum late in the sequence
         sd['pos_embed'][0, :, c[5]] *= 20.0
         blk = min(depth - 2, 6)
         wq = sd[f'blocks.{blk}.attn.qkv.weight']
-        for head, ch, a in ((1 % heads, c[0], 0.5), (2 % heads, c[5], 0.6)):
+        for head, ch, a in ((1 % heads, c[0], 0.5), (2 % heads, c[5], 0.5)):
             wq[head * 64:(head + 1) * 64, ch] += a
             wq[dim + head * 64:dim + (head + 1) * 64, ch] += a
     return sd
