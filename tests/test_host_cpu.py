@@ -208,14 +208,14 @@ def test_bench_pmc_traffic_only_for_the_measured_kernel(tmp_path, monkeypatch):
 
 
 def test_engine_batch_follows_a_workspace_budget(monkeypatch):
-    """Slices per engine call: 256 at the metric's shape, scaled down with the token count and the width so that the
-    workspace stays where 256 x 4097 x 384 puts it; an explicit request or VITTF_ENGINE_BATCH wins."""
+    """Slices per engine call: 256 at the metric's shape, scaled down with the token count so that a call's row count stays
+    where 256 x 4097 puts it; an explicit request or VITTF_ENGINE_BATCH wins."""
     from vit_tf_amd.extract import engine_batch_for
     monkeypatch.delenv('VITTF_ENGINE_BATCH', raising=False)
     assert engine_batch_for(4097, 384) == 256
     assert engine_batch_for(16385, 384) == 64          # sub/infer_and_merge.sh: fos 128, 1024 x 1024 slices
-    assert engine_batch_for(4097, 768) == 128          # ViT-B/8
-    assert engine_batch_for(16385, 768) == 32
+    assert engine_batch_for(4097, 768) == 256          # ViT-B/8: the same rows per call (11 GB of workspace)
+    assert engine_batch_for(16385, 768) == 64
     assert engine_batch_for(65, 384) == 256 and engine_batch_for(10 ** 9, 384) == 1
     assert engine_batch_for(4097, 384, 32) == 32
     monkeypatch.setenv('VITTF_ENGINE_BATCH', '8')

@@ -26,17 +26,19 @@ DEFAULT_ENGINE_BATCH = 256
 
 
 def engine_batch_for(tokens, embed_dim, requested=None):
-    """Slices per engine call.  The default keeps the workspace at what 256 slices of N = 4097, D = 384 take (~5.6 GB per
-    stream lane) whatever the token count and width: 256 * 4097 * 384 / (tokens * D), clamped to 1 .. 256 -- the fos-128
-    preset (N = 16385) then runs 64 slices per call, ViT-B/8 128.  `requested` (infer.py --batch-size > 1, bench.py
-    --engine-batch) or VITTF_ENGINE_BATCH lower or raise it; results never depend on it."""
+    """Slices per engine call.  The default keeps the ROW count of a call at what 256 slices of N = 4097 are (1.05 M rows:
+    5.6 GB of workspace per stream lane at D = 384, 11 GB at D = 768; the widest buffer, rows x 4 D 16-bit values, stays
+    below 2^32 elements), whatever the token count: 256 * 4097 / tokens, clamped to 1 .. 256 -- the fos-128 preset
+    (N = 16385) then runs 64 slices per call.  `requested` (infer.py --batch-size > 1, bench.py --engine-batch) or
+    VITTF_ENGINE_BATCH lower or raise it; results never depend on it."""
     env = __import__('os').environ.get('VITTF_ENGINE_BATCH')
     if env:
         return max(1, int(env))
     if requested:
         return max(1, int(requested))
-    budget = DEFAULT_ENGINE_BATCH * 4097 * 384
-    return max(1, min(DEFAULT_ENGINE_BATCH, budget // (int(tokens) * int(embed_dim))))
+    return max(1, min(DEFAULT_ENGINE_BATCH, DEFAULT_ENGINE_BATCH * 4097 // int(tokens)))
+
+
 # Batches of slices are independent, so consecutive batches can go round-robin onto several HIP streams (each with
 # its own workspace): the VALU/MFMA-bound attention of one batch then overlaps the HBM-bound LayerNorm / GEMM
 # epilogues of another and covers the under-filled last wave of workgroups of every launch.  Measured +5.9 % slices/s
