@@ -39,6 +39,8 @@ for s in "$@"; do
               python tools/pmc_json.py similarity $OUT/pmc_sim.log sim_mfma_few $OUT/pmc_similarity.json batch=16 nvox=262144 features=384 kernel=sim_mfma_few_kernel > /dev/null ;;
     fp8)      step test_fp8 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -q -m gpu -s -p no:cacheprovider -k "fp8 or vitb8" ;;
     benchb)   for a in 16bit fp8; do VITTF_BENCH_OVERLAP=0 step benchb_$a 600 python bench.py --arch vitb8 --workload 64 --attention $a --cpu-slices 0 --steps 2; done ;;
+    benchb512) for a in 16bit fp8; do VITTF_BENCH_OVERLAP=0 step benchb512_$a 600 python bench.py --arch vitb8 --attention $a --cpu-slices 0 --steps 2; done ;;
+    simmany)  step sim_many 300 python tools/sim_many_profile.py ;;
     simtests) step test_sim 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider -k "similarity or sim or golden or labels or cosine or topk" ;;
     prof8)    cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               SETTLE_S=0.05 step prof8 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof8 -- python tools/bench_kernels.py attn8 ;;
