@@ -77,9 +77,10 @@ typedef struct vittf_vit_weights {
   const float* fc1_b;    /* [L][4D] */
   const void*  fc2_w;    /* h16 [L][D][4D]   blocks.i.mlp.fc2.weight */
   const float* fc2_b;    /* [L][D] */
-  const void*  fc2_w_perm; /* h16 [L][D][4D] or NULL: fc2_w with the hidden (input) dim re-ordered inside every block of
-                            16 as [0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15] -- the operand order of vittf_mlp_fused;
-                            when non-NULL and D == 384 the engine runs the fused MLP kernel */
+  const void*  mlp_packed; /* h16 [L][96][12288] or NULL: fc1_w and fc2_w of every block as the stream of 24 KB LDS images the
+                            fused MLP kernel consumes (vittf_mlp_fused; packing: vit-tf_amd/weights.py pack_mlp_weights);
+                            when non-NULL and D == 384 the engine runs fc1 -> GELU -> fc2 -> residual -> next LayerNorm as
+                            one launch instead of two GEMMs */
   const float* ln1_g;    /* [L][D] */
   const float* ln1_b;    /* [L][D] */
   const float* ln2_g;    /* [L][D] */
@@ -194,11 +195,12 @@ int vittf_ln_gemm(const float* x, const float* ln_g, const float* ln_b, float ln
                   void* out, int64_t rows, int32_t n, int32_t k, int32_t epilogue, int32_t dtype, void* stream);
 
 /* Fused MLP of one block for D == 384:  x[rows][D] (fp32) += fc2(gelu_erf(fc1(h) + b1)) + b2 without ever writing the
- * [rows][4D] hidden activation.  h: h16 [rows][D] (LayerNorm2 output); w1: h16 [4D][D]; w2_perm: h16 [D][4D] in the
- * vittf_vit_weights.fc2_w_perm order.  Same result as vittf_gemm(BIAS_GELU) + vittf_gemm(BIAS_RESIDUAL) up to the
- * rounding of the hidden activation (identical: both round it once to h16). */
-int vittf_mlp_fused(const void* h, const void* w1, const float* b1, const void* w2_perm, const float* b2, float* x,
-                    int64_t rows, int32_t d, int32_t dtype, void* stream);
+ * [rows][4D] hidden activation, and -- when ln_g / ln_b / h_out are given -- h_out[rows][D] (h16) = LayerNorm(x_new; ln_g,
+ * ln_b, ln_eps) on the way out (the next block's norm1).  h: h16 [rows][D] (LayerNorm2 output); w_packed: h16 [96][12288], one
+ * block of vittf_vit_weights.mlp_packed.  Same result as vittf_gemm(BIAS_GELU) + vittf_gemm_residual_ln up to the fp32
+ * summation order of fc2 (the hidden activation is identical: both round it once to h16). */
+int vittf_mlp_fused(const void* h, const void* w_packed, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
+                    int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* stream);
 
 /* Multi-head self-attention over `batch` independent sequences of `tokens` rows.
  * qkv h16 [batch*tokens][3D] with columns [q | k | v], heads of 64 concatenated inside each third

@@ -109,10 +109,11 @@ def test_gemm_rejects_bad_shapes(gpu):
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-@pytest.mark.parametrize('rows', [1, 130, 4097])
-def test_mlp_fused(gpu, dt, rows):
-    """x += fc2(gelu(fc1(h))) with the hidden activation kept in registers, against fp64 (hidden rounded once to the
-    16-bit type, as both the fused and the two-GEMM path do) and against the two-GEMM path itself."""
+@pytest.mark.parametrize('rows,with_ln', [(1, True), (130, True), (4097, False), (4097, True), (128 * 300 + 77, True)])
+def test_mlp_fused(gpu, dt, rows, with_ln):
+    """x += fc2(gelu(fc1(h))) with the hidden activation kept in registers (+ the LayerNorm of the new rows), against fp64
+    (hidden rounded once to the 16-bit type, as both the fused and the two-GEMM path do) and against the two-GEMM path
+    itself; 300 row tiles + a partial one: more tiles than persistent workgroups, the weight stream wraps many times."""
     lib = _lib.load()
     d = 384
     g = gen(rows)
@@ -121,29 +122,39 @@ def test_mlp_fused(gpu, dt, rows):
     b1 = 0.3 * torch.randn(4 * d, generator=g)
     w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
     b2 = 0.3 * torch.randn(d, generator=g)
+    lg, lb = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
     x0 = torch.randn(rows + 2, d, generator=g) * 3
-    hid = F.gelu(h.double() @ w1.double().t() + b1.double()).to(TDT[dt]).double()
-    ref = x0[:rows].double() + hid @ w2.double().t() + b2.double()
-    hd, w1d, b1d, w2d, b2d = h.to(gpu), w1.to(gpu), b1.to(gpu), w2.to(gpu), b2.to(gpu)
-    w2p = vt.weights.permute_fc2_hidden(w2).to(gpu)
+    hd, w1d, b1d, w2d, b2d, lgd, lbd = (t.to(gpu) for t in (h, w1, b1, w2, b2, lg, lb))
+    hid = F.gelu(hd.double() @ w1d.double().t() + b1d.double()).to(TDT[dt]).double()
+    ref = (x0[:rows].to(gpu).double() + hid @ w2d.double().t() + b2d.double()).cpu()
+    wpk = vt.weights.pack_mlp_weights(w1d[None], w2d[None])[0].contiguous()
+    assert wpk.shape == (96, 12288)
     xd = x0.to(gpu)
-    _lib.check(lib.vittf_mlp_fused(_lib.ptr(hd), _lib.ptr(w1d), _lib.ptr(b1d), _lib.ptr(w2p), _lib.ptr(b2d), _lib.ptr(xd), rows,
-                                   d, _lib.DTYPES[dt], _lib.stream_ptr()))
+    hn = torch.full((rows + 2, d), 7.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_mlp_fused(_lib.ptr(hd), _lib.ptr(wpk), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(xd), rows, d, _lib.DTYPES[dt],
+                                   _lib.ptr(lgd) if with_ln else None, _lib.ptr(lbd) if with_ln else None, 1e-6,
+                                   _lib.ptr(hn) if with_ln else None, _lib.stream_ptr()))
     got = xd.cpu().double()
     assert torch.equal(got[rows:], x0[rows:].double()), 'wrote past the last row'
     # a hidden unit whose fp32 pre-activation sits on a rounding boundary may round the other way than in fp64
     assert ((got[:rows] - ref).abs() <= 3 * EPS[dt] + 1e-4).all()
     assert rel_fro(got[:rows] - x0[:rows].double(), ref - x0[:rows].double()) <= EPS[dt] / 4
-    # the unfused path: fc1 + GELU GEMM, then fc2 + residual GEMM
+    # the unfused path: fc1 + GELU GEMM, then fc2 + residual (+ LayerNorm) GEMM
     gbuf = torch.zeros(rows, 4 * d, dtype=TDT[dt], device=gpu)
     x2 = x0.to(gpu)
+    h2 = torch.zeros(rows, d, dtype=TDT[dt], device=gpu)
     _lib.check(lib.vittf_gemm(_lib.ptr(hd), _lib.ptr(w1d), _lib.ptr(b1d), _lib.ptr(gbuf), rows, 4 * d, d, _lib.EPI_BIAS_GELU, 0,
                               _lib.DTYPES[dt], _lib.stream_ptr()))
-    _lib.check(lib.vittf_gemm(_lib.ptr(gbuf), _lib.ptr(w2d), _lib.ptr(b2d), _lib.ptr(x2), rows, d, 4 * d,
-                              _lib.EPI_BIAS_RESIDUAL, 0, _lib.DTYPES[dt], _lib.stream_ptr()))
+    _lib.check(lib.vittf_gemm_residual_ln(_lib.ptr(gbuf), _lib.ptr(w2d), _lib.ptr(b2d), _lib.ptr(x2), rows, d, 4 * d, _lib.DTYPES[dt],
+                                          _lib.ptr(lgd), _lib.ptr(lbd), 1e-6, _lib.ptr(h2), _lib.stream_ptr()))
     assert torch.allclose(xd[:rows], x2[:rows], rtol=0, atol=2e-4 * float(ref.abs().max()))
-    assert lib.vittf_mlp_fused(_lib.ptr(hd), _lib.ptr(w1d), _lib.ptr(b1d), _lib.ptr(w2p), _lib.ptr(b2d), _lib.ptr(xd), rows,
-                               768, _lib.DTYPES[dt], _lib.stream_ptr()) == -1
+    if with_ln:
+        assert (hn[rows:].float() == 7.0).all(), 'wrote past the last row of h'
+        want = F.layer_norm(got[:rows], (d,), lg.double(), lb.double(), 1e-6)
+        assert ((hn[:rows].cpu().double() - want).abs() <= 2 * EPS[dt] * (1 + want.abs())).all()
+        assert torch.allclose(hn[:rows].float(), h2.float(), rtol=0, atol=4 * EPS[dt] * float(want.abs().max()))
+    assert lib.vittf_mlp_fused(_lib.ptr(hd), _lib.ptr(wpk), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(xd), rows, 768, _lib.DTYPES[dt],
+                               None, None, 1e-6, None, _lib.stream_ptr()) == -1
 
 
 # ------------------------------------------------------------------------------------------ attention

@@ -144,13 +144,16 @@ def main():
     if 'mlp' in what:
         hh = torch.randn(rows, d, generator=g).to(TDT[dt]).to(dev)
         w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(dev)
-        w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
-        w2p = vt.weights.permute_fc2_hidden(w2).to(dev)
+        w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt]).to(dev)
+        wpk = vt.weights.pack_mlp_weights(w1[None], w2[None])[0].contiguous()
         b1 = torch.randn(4 * d, generator=g).to(dev); b2 = torch.randn(d, generator=g).to(dev)
-        xx = torch.zeros(rows, d, device=dev)
-        ms = timeit(lambda: _lib.check(lib.vittf_mlp_fused(_lib.ptr(hh), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2p), _lib.ptr(b2), _lib.ptr(xx), rows, d, _lib.DTYPES[dt], _lib.stream_ptr())))
-        fl = 16 * rows * d * d
-        print(f'mlp fused  [{rows}x{d}] -> {4 * d} -> {d}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s   (two-GEMM path: fc1+gelu + fc2+res above)')
+        x = torch.zeros(rows, d, device=dev)
+        lg = torch.ones(d, device=dev); lb = torch.zeros(d, device=dev)
+        hn = torch.empty(rows, d, dtype=TDT[dt], device=dev)
+        ms = timeit(lambda: _lib.check(lib.vittf_mlp_fused(_lib.ptr(hh), _lib.ptr(wpk), _lib.ptr(b1), _lib.ptr(b2), _lib.ptr(x), rows, d,
+                                                            _lib.DTYPES[dt], _lib.ptr(lg), _lib.ptr(lb), 1e-6, _lib.ptr(hn), _lib.stream_ptr())))
+        fl = 4 * rows * d * 4 * d
+        print(f'fused mlp + ln [{rows}x{d}]: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({ms * 32 / batch:.4f} ms per 32 slices)')
     if 'ln' in what:
         x = torch.randn(rows, d, generator=g).to(dev)
         w = torch.ones(d, device=dev); b = torch.zeros(d, device=dev)

@@ -131,11 +131,11 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   // Parity-green, but the fp32 rows are then fetched once per 384-column panel (3-4 x 201 MB instead of 3-4 x 100 MB of
   // 16-bit rows), which costs more than the LayerNorm launches: 1690 against 1720 slices/s on the 256^3 workload.
   static const bool ln_fused_env = [] { const char* e = getenv("VITTF_LN_FUSED"); return e && atoi(e) != 0; }();
-  const bool ln_fused = ln_fused_env && d == 384 && !(w->fc2_w_perm);
+  const bool ln_fused = ln_fused_env && d == 384 && !(w->mlp_packed);
   // Default (D = 384 / 768): every LayerNorm but the first rides on the epilogue of the residual GEMM in front of it
   // (vittf_gemm_residual_ln: proj -> norm2, fc2 -> the next block's norm1); VITTF_RESIDUAL_LN=0 keeps them separate.
   static const bool res_ln_env = [] { const char* e = getenv("VITTF_RESIDUAL_LN"); return !e || atoi(e) != 0; }();
-  const bool res_ln = res_ln_env && (d == 384 || d == 768) && !ln_fused && !(w->fc2_w_perm);
+  const bool res_ln = res_ln_env && (d == 384 || d == 768) && !ln_fused;
   for (int l = 0; l < L; ++l) {
     const char* qkv_w = (const char*)w->qkv_w + (size_t)l * 3 * d * d * esz;
     if (res_ln ? l == 0 : (!ln_fused || l == L - 1)) {
@@ -181,11 +181,12 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
       rc = vittf_layernorm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
       if (rc) return rc;
     }
-    if (d == 384 && w->fc2_w_perm) {
+    if (d == 384 && w->mlp_packed) {
+      // fc1 -> GELU -> fc2 -> residual (-> the next block's norm1) in one launch: the hidden activation stays on the chip
       ProfScope ps(VITTF_KERNEL_MLP, stream);
-      rc = vittf_mlp_fused(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d,
-                           (const char*)w->fc2_w_perm + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
-                           dt, stream);
+      rc = vittf_mlp_fused(H, (const char*)w->mlp_packed + (size_t)l * 4 * d * d * 2 * esz, w->fc1_b + (size_t)l * 4 * d,
+                           w->fc2_b + (size_t)l * d, X, rows, d, dt, res_ln ? w->ln1_g + (size_t)(l + 1) * d : nullptr,
+                           res_ln ? w->ln1_b + (size_t)(l + 1) * d : nullptr, cfg->ln_eps, res_ln ? H : nullptr, stream);
       if (rc) return rc;
     } else {
       { ProfScope ps(VITTF_KERNEL_GEMM_FC1, stream);

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .weights import arch_of, fold_patch_embed, interpolate_pos_embed, permute_fc2_hidden
+from .weights import arch_of, fold_patch_embed, interpolate_pos_embed, pack_mlp_weights
 
 _TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.FP16: torch.float16}
 
@@ -68,13 +68,13 @@ class HipViT:
             'ln2_g': stack('blocks.{}.norm2.weight', torch.float32), 'ln2_b': stack('blocks.{}.norm2.bias', torch.float32),
         }
         ptrs = {k: v.data_ptr() for k, v in self._t.items()}
-        ptrs['fc2_w_perm'] = None
-        if fused_mlp is None:                   # opt-in: parity-green but not yet faster than the two GEMMs (mlp.hip)
+        ptrs['mlp_packed'] = None
+        if fused_mlp is None:                   # D = 384: the fused fc1 -> GELU -> fc2 (+ LayerNorm) kernel (csrc/mlp.hip)
             import os
-            fused_mlp = os.environ.get('VITTF_FUSED_MLP', '0') == '1'
+            fused_mlp = os.environ.get('VITTF_FUSED_MLP', '1') == '1'
         if fused_mlp and dim == 384:           # the fused MLP kernel's register budget is sized for ViT-S
-            self._t['fc2_w_perm'] = permute_fc2_hidden(self._t['fc2_w'])
-            ptrs['fc2_w_perm'] = self._t['fc2_w_perm'].data_ptr()
+            self._t['mlp_packed'] = pack_mlp_weights(self._t['fc1_w'], self._t['fc2_w'])
+            ptrs['mlp_packed'] = self._t['mlp_packed'].data_ptr()
         self.weights = _lib.VitWeights(**ptrs)
         self._cls = sd['cls_token'].reshape(1, 1, dim)
         self._pos = sd['pos_embed']

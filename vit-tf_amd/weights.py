@@ -186,6 +186,47 @@ def interpolate_pos_embed(pos_embed, rows, cols, patch):
 FC2_PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
 
 
+def _tile_pos_tables():
+    """(row, chunk) held by each of the 256 16-byte positions of a [32 rows][64 x 16-bit] sub-image in the kernels' tile_off
+    layout (vittf_common.h: tile_pos)."""
+    q = torch.arange(256)
+    p = q >> 4
+    slot = (q & 15) ^ (p & 15)
+    return (p << 1) | (slot >> 3), slot & 7
+
+
+def pack_mlp_weights(w1, w2):
+    """fc1 / fc2 weights of L blocks -> the stream the fused MLP kernel (csrc/mlp.hip) consumes: per block 96 images of
+    24 KB in consumption order W1(0), W1(1), W1(2), W2(0), W1(3), W2(1), .., W1(47), W2(45), W2(46), W2(47), each image = 6 sub-images of
+    [32 rows][64 k] in LDS layout, so that every LDS-DMA piece is 1 KB of contiguous memory.
+      W1(u): rows = hidden units 32 u .. + 31, k = the 384 inputs.
+      W2(u): rows = outputs; sub-image s6 holds output tiles 2 s6 and 2 s6 + 1, 32 k each = hidden units 32 u .. + 31 in the
+             order the second MFMA finds them in the first one's accumulator registers (permute_fc2_hidden).
+    w1: [L, 4D, D], w2: [L, D, 4D] (16-bit, any device).  Returns [L, 96, 12288] of the same dtype."""
+    L, hid, d = w1.shape
+    assert d == 384 and hid == 4 * d and tuple(w2.shape) == (L, d, hid)
+    units = hid // 32
+    dev = w1.device
+    r, c = (t.to(dev) for t in _tile_pos_tables())                      # [256]
+    e = torch.arange(8, device=dev)
+    s6 = torch.arange(6, device=dev)
+    # W1(u): element (s6, q, e) = w1[32 u + r[q], 64 s6 + 8 c[q] + e]
+    rows1 = torch.arange(units, device=dev).view(-1, 1, 1, 1) * 32 + r.view(1, 1, -1, 1)               # [U, 1, 256, 1]
+    cols1 = (64 * s6.view(1, -1, 1, 1) + 8 * c.view(1, 1, -1, 1) + e.view(1, 1, 1, -1))                 # [1, 6, 256, 8]
+    img1 = w1[:, rows1.expand(units, 6, 256, 8), cols1.expand(units, 6, 256, 8)].reshape(L, units, -1)
+    # W2(u): element (s6, q, e) = w2p[32 (2 s6 + (c >> 2)) + r, 32 u + 16 ((c >> 1) & 1) + 8 (c & 1) + e]
+    w2p = permute_fc2_hidden(w2)
+    rows2 = (32 * (2 * s6.view(1, -1, 1, 1) + (c.view(1, 1, -1, 1) >> 2)) + r.view(1, 1, -1, 1))       # [1, 6, 256, 1]
+    cols2 = (32 * torch.arange(units, device=dev).view(-1, 1, 1, 1) + 16 * ((c.view(1, 1, -1, 1) >> 1) & 1)
+             + 8 * (c.view(1, 1, -1, 1) & 1) + e.view(1, 1, 1, -1))                                     # [U, 1, 256, 8]
+    img2 = w2p[:, rows2.expand(units, 6, 256, 8), cols2.expand(units, 6, 256, 8)].reshape(L, units, -1)
+    order = [('1', 0), ('1', 1)]
+    for k in range(2, units):
+        order += [('1', k), ('2', k - 2)]
+    order += [('2', units - 2), ('2', units - 1)]
+    return torch.stack([(img1 if t == '1' else img2)[:, u] for t, u in order], dim=1).contiguous()
+
+
 def permute_fc2_hidden(w2):
     """fc2 weight [..., D, 4D] with its hidden (input) dim re-ordered inside every block of 16: the k order in which
     the fused MLP kernel's second MFMA consumes the first one's accumulator registers (include/vittf.h, fc2_w_perm)."""
