@@ -220,3 +220,26 @@ def test_engine_batch_follows_a_workspace_budget(monkeypatch):
     assert engine_batch_for(4097, 384, 32) == 32
     monkeypatch.setenv('VITTF_ENGINE_BATCH', '8')
     assert engine_batch_for(4097, 384, 32) == 8
+
+
+def test_fused_mlp_kernel_register_contract():
+    """csrc/mlp.hip runs one wave per SIMD on all 512 registers with hand-counted vmcnt waits: a single spill adds scratch
+    loads the counts do not know of (and s_waitcnt vmcnt(0) in front of their uses), and its LDS-DMA pieces leave M0
+    pointing at their destination, which is only sound while hipcc keeps nothing of its own in M0.  Both are properties of
+    the generated code, so they are checked on it (the flags are the Makefile's: tools/kernel_asm.sh)."""
+    import re
+    import shutil
+    if not shutil.which('/opt/rocm/bin/hipcc'):
+        pytest.skip('no hipcc')
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'kernel_asm.sh'), 'mlp.hip'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    usage = [l for l in r.stdout.splitlines() if 'mlp_kernel' in l and 'ScratchSize' in l]
+    assert len(usage) == 2, r.stdout                                       # bf16 and fp16
+    for l in usage:
+        assert 'ScratchSize [bytes/lane]: 0 ' in l and 'VGPRs Spill: 0' in l and 'Occupancy [waves/SIMD]: 1' in l, l
+    asm = open('/tmp/vittf_asm/mlp.s').read()
+    body = asm[asm.index('mlp_kernel'):]
+    m0 = [l.strip() for l in body.splitlines() if re.search(r'\bm0\b', l) and not l.strip().startswith(';')]
+    ours = r's_mov_b32 (m0, s\d+|s\d+, m0)'          # lds_dma16_keep, and the prologue's lds_dma16 (saves and restores)
+    assert m0 and all(re.fullmatch(ours, l) for l in m0), [l for l in m0 if not re.fullmatch(ours, l)][:5]
+    assert 'flat_load' not in body and 'scratch_' not in body

@@ -8,7 +8,7 @@
 // L2 at the same time (2.36 MB per layer), and one pass over h / x.
 //
 // Machine mapping (gfx950; round 3 -- the round-1 kernel of this file had the same data flow but ran its phases one after
-// the other: 0.66 ms per 32 slices against 0.44 for the two GEMMs):
+// the other: 0.66 ms per 32 slices against 0.44 for the two GEMMs; this one 0.36):
 //   * workgroup = 4 waves = 128 rows, ONE wave per SIMD with the whole 512-entry register file, persistent over row tiles.
 //     Both products are computed transposed (weights = MFMA A operand, activations = B operand, a lane owns one row): a
 //     wave keeps its 32 rows' LayerNorm output as 24 B operands (96 registers) and the full 384-wide output as 12
@@ -21,10 +21,16 @@
 //     piece is 1 KB of contiguous memory.  Six ring slots, five units requested ahead, one barrier per unit, counted vmcnt.
 //   * software pipeline, pinned per MFMA gap (one wave per SIMD: nothing else fills the gaps): the 24 A fragments of a
 //     unit are read through 8 fragment registers refilled in place right behind the MFMA that used them (the reads run 8
-//     MFMAs ahead, across unit boundaries); the GELU of unit u runs in the gaps of fc1(u + 1); the six DMA pieces a wave
-//     issues per unit sit behind every fourth MFMA.
-//   * epilogue per tile: 16-byte read-modify-write of the fp32 residual rows, two-pass LayerNorm in the same registers
-//     (the other half of a row is in the lane 32 further on), 8-byte stores of the 16-bit h.
+//     MFMAs ahead, across unit boundaries); fc1 runs two hidden units ahead of fc2 and the GELU of the unit in between is
+//     cut into thirds of a value per gap over both (a one-wave SIMD hides about 24 issue cycles beside an MFMA, a whole
+//     value is 46); the six DMA pieces a wave issues per unit sit behind every fourth MFMA.
+//   * between two tiles: drain, then per output tile the fp32 residual comes in and the sum goes out THROUGH LDS (a lane
+//     owns a row, so direct accesses would be 32-byte runs, which a CU's memory path takes at 7 bytes per cycle; through
+//     the staging space they are 128-byte runs), the two-pass LayerNorm runs in the same registers (the other half of a
+//     row is in the lane 32 further on), h goes out the same way, and the next tile's h fragments are requested before all
+//     of that.  Measured per 128-row tile (tools/mlp_variants.py, stamps): 160 thousand cycles = 8 for the first six units
+//     + 105 for the other 90 (1170 per unit against 768 of bare MFMA: 173 LDS-DMA issue, 83 fragment reads, 141 GELU)
+//     + 45 for the epilogue, which moves its 590 KB per CU at the CU's share of the HBM rate (all CUs get there together).
 #include "vittf_common.h"
 
 #include <stdlib.h>
@@ -40,14 +46,15 @@ constexpr int NF = 8;                      // fragment registers in flight
 constexpr int PIECES = UB / 1024 / 4;      // LDS-DMA pieces per wave and unit
 constexpr int CONST_OFF = NSLOT * UB;      // b1 [1536] | b2 [384] | gamma [384] | beta [384] as fp32 behind the ring
 constexpr int LDS_BYTES = CONST_OFF + (HID + 3 * D) * 4;
+constexpr int STG_ROW = 144, STG_BYTES = UB / 4;          // epilogue staging: 32 rows of 128 bytes + 16 per wave, in a quarter of a ring slot
+static_assert(32 * STG_ROW <= STG_BYTES, "staging");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 
 struct TileIO {                // a row tile's activations: descriptors that end with the tile's last valid row (loads past it
-  __amdgpu_buffer_rsrc_t x, h_next, h_out;    // return 0, stores are dropped) and this lane's byte offsets into them
-  int xoff, hoff, hooff;       // x: row * 1536 + 16 h;  h in: row * 768 + 16 h;  h out: row * 768 + 8 h
+  __amdgpu_buffer_rsrc_t x, h_next, h_out;    // return 0, stores are dropped)
 };
 
 struct Stream {                // where the weight stream stands (wave-uniform)
@@ -63,6 +70,8 @@ struct Stream {                // where the weight stream stands (wave-uniform)
 typedef __attribute__((address_space(3))) const s16x8_t* lds_frag_ptr;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((address_space(3))) const f32x4_t* lds_f4_ptr;
+typedef __attribute__((address_space(3))) f32x4_t* lds_w4_ptr;
+typedef __attribute__((address_space(3))) u32x2_t* lds_w2_ptr;
 __device__ __forceinline__ s16x8_t ld_frag(const unsigned (&base)[4], int f) {
   return *(lds_frag_ptr)(base[f & 3] + (f >> 2) * 4096);
 }
@@ -71,20 +80,14 @@ __device__ __forceinline__ s16x8_t ld_frag(const unsigned (&base)[4], int f) {
 #ifndef MLP_VARIANT
 #define MLP_VARIANT 0
 #endif
-#ifndef MLP_HP
-#define MLP_HP 2
-#endif
-#if MLP_VARIANT & 16      // in-kernel stamps: s_memtime (shader cycles) | s_memrealtime (100 MHz) at eight points of a tile
+#if MLP_VARIANT & 16      // in-kernel stamps: s_memtime (shader cycles) at eight points of a tile, kept in SGPRs until its end
 __device__ unsigned long long g_mlp_stamps[4 /*workgroups*/][4 /*tiles*/][4 /*waves*/][8][2];
 #define MLP_STAMP(k)                                                                                          \
   do {                                                                                                        \
-    if (blockIdx.x < 4 && tile_no < 4) {                                                                      \
-      unsigned long long t0_, t1_;                                                                            \
-      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_), "=s"(t1_)::"memory");  \
-      if ((threadIdx.x & 63) == 0) {                                                                          \
-        g_mlp_stamps[blockIdx.x][tile_no][threadIdx.x >> 6][k][0] = t0_;                                      \
-        g_mlp_stamps[blockIdx.x][tile_no][threadIdx.x >> 6][k][1] = t1_;                                      \
-      }                                                                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_[k])::"memory");                       \
+    if (k == 7 && blockIdx.x < 4 && tile_no < 4 && (threadIdx.x & 63) == 0) {                                 \
+      _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                        \
+        g_mlp_stamps[blockIdx.x][tile_no][threadIdx.x >> 6][q_][0] = stamp_[q_];                              \
     }                                                                                                         \
   } while (0)
 #else
@@ -124,17 +127,19 @@ __device__ __forceinline__ float gelu_c(const Gelu3& s, float x) {
 // One unit of the stream = 24 MFMAs.  FC1: gacc = W1u . h^T (+ the bias tile as initial value); FC2: xacc[ot] += W2u . gf_in.
 // GH: which part of the activation of the fc1 tile gprev runs in this unit's gaps -- 0 none, 1 values 0 .. 7 -> gf_out[0],
 // 2 values 8 .. 15 -> gf_out[1] (one value per three gaps, a third of it in each), 3 all sixteen (first / last units of a tile).
-template <int DT, bool FC1, int GH, int WAITN = 3 * PIECES, int XL = -1, bool HP = false, bool LAST = false>
+// WAITN < 0: no counted wait (see the kernel); ZI: a tile's first fc2 unit, its accumulators start from zero; LAST: a tile's
+// last unit reads no fragments ahead.
+template <int DT, bool FC1, int GH, int WAITN = 3 * PIECES, bool ZI = false, bool LAST = false>
 __device__ __forceinline__ void mlp_unit(Stream& st, unsigned (&base)[4], s16x8_t (&wf)[NF], s16x8_t (&hf)[D / 16],
                                          f32x16_t (&xacc)[D / 32], f32x16_t& gacc, const f32x16_t& bias_c,
-                                         const f32x16_t& gprev, s16x8_t (&gf_out)[2], const s16x8_t (&gf_in)[2],
-                                         const TileIO& io) {
+                                         const f32x16_t& gprev, s16x8_t (&gf_out)[2], const s16x8_t (&gf_in)[2]) {
   // the unit's image was requested AHEAD units ago; of what this wave issued since only the pieces of the three units behind
   // the NEXT one may still be in flight: the next unit's image has landed too (its fragments are read from MFMA 16 on).
-  // WAITN = those 18 pieces + the other loads / stores the wave has issued in the last three units (vmcnt counts them all, in
-  // order; at most 63).  The barrier also says that everybody is done with the slot of the unit before this one, refilled below.
-  static_assert(WAITN <= 63 && WAITN >= 3 * PIECES, "vmcnt");
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(V_NO_DMA ? 0 : WAITN) : "memory");
+  // (vmcnt counts every load and store of the wave, in order: the units issue nothing but these pieces.)  The barrier also
+  // says that everybody is done with the slot of the unit before this one, which is refilled below.
+  static_assert(WAITN < 0 || WAITN == 3 * PIECES, "vmcnt");
+  if constexpr (WAITN < 0) asm volatile("s_barrier" ::: "memory");      // (the tile's first units: everything landed before the epilogue)
+  else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(V_NO_DMA ? 0 : WAITN) : "memory");
   const int g_next = st.g + AHEAD < NSEQ ? st.g + AHEAD : st.g + AHEAD - NSEQ;       // (the stream wraps: the next row tile)
   const int slot_free = st.slot == 0 ? NSLOT - 1 : st.slot - 1;
   u32x4_t pk0 = {}, pk1 = {};
@@ -143,7 +148,7 @@ __device__ __forceinline__ void mlp_unit(Stream& st, unsigned (&base)[4], s16x8_
 #pragma unroll
   for (int j = 0; j < 24; ++j) {
     if constexpr (FC1) gacc = mfma32<DT>(wf[j % NF], hf[j], j == 0 ? bias_c : gacc);
-    else xacc[j >> 1] = mfma32<DT>(wf[j % NF], gf_in[j & 1], xacc[j >> 1]);
+    else xacc[j >> 1] = mfma32<DT>(wf[j % NF], gf_in[j & 1], ZI && !(j & 1) ? f32x16_t{} : xacc[j >> 1]);
     if (j == 24 - NF) {                        // from here on the refills read the next unit's image
       const int d_ = st.slot == NSLOT - 1 ? -(NSLOT - 1) * UB : UB;
 #pragma unroll
@@ -156,16 +161,6 @@ __device__ __forceinline__ void mlp_unit(Stream& st, unsigned (&base)[4], s16x8_
       if (V_M0_KEEP) lds_dma16(st.rsrc, dst, (int)((threadIdx.x & 63) * 16), src);
       else lds_dma16_keep(st.rsrc, dst, (int)((threadIdx.x & 63) * 16), src);
     }
-    if constexpr (XL >= 0) {                   // a third of the tile's residual rows -> the fc2 accumulators' initial value
-      if (j % 3 != 2) {                        // (16 x 16 bytes per lane; first needed three units on)
-        const int i = 2 * (j / 3) + j % 3, ot = 4 * XL + (i >> 2), g = i & 3;
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(io.x, io.xoff, (32 * ot + 8 * g) * 4, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xacc[ot][4 * g + e] = __uint_as_float(v[e]);
-      }
-    }
-    if constexpr (HP)                          // fc1 is done with the tile: the next one's h
-      hf[j] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(io.h_next, io.hoff, 32 * j, 0));
     if constexpr (GH == 1 || GH == 2) {
       const int r = (GH == 2 ? 8 : 0) + j / 3;
       if (V_NO_GELU) {
@@ -249,21 +244,19 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
                                              nrows * row_bytes, 0x00020000);
   };
   TileIO io;
-  io.xoff = (wave * 32 + l31) * (D * 4) + 16 * h;
-  io.hoff = (wave * 32 + l31) * (D * 2) + 16 * h;
-  io.hooff = (wave * 32 + l31) * (D * 2) + 8 * h;
   // ---- this lane's h fragments (B operand) of the first tile: H[row][16 s + 8 h .. + 7], s = 0 .. 23 ----
   s16x8_t hf[D / 16];
   {
     const auto rs = tile_rsrc(hbuf, blockIdx.x, D * 2);
 #pragma unroll
-    for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, io.hoff, 32 * s, 0));
+    for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (wave * 32 + l31) * (D * 2) + 16 * h, 32 * s, 0));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first AHEAD images have landed (only here: the unit waits count
   __syncthreads();                                       // on a steady stream) ... everybody's pieces; the constants are written
   s16x8_t wf[NF];
 
   [[maybe_unused]] int tile_no = -1;
+  [[maybe_unused]] unsigned long long stamp_[8];
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     ++tile_no;
     MLP_STAMP(0);
@@ -273,14 +266,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
 #pragma unroll
     for (int f = 0; f < NF; ++f) wf[f] = ld_frag(base, f);
     io.x = tile_rsrc(x, tile, D * 4);
-    if (MLP_HP == 0 && tile != (int)blockIdx.x) {
-      const auto rs = tile_rsrc(hbuf, tile, D * 2);
-#pragma unroll
-      for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, io.hoff, 32 * s, 0));
-    }
     io.h_next = tile_rsrc(hbuf, (int64_t)tile + gridDim.x, D * 2);      // (no next tile: an empty descriptor)
     io.h_out = tile_rsrc(hout, tile, D * 2);
-    f32x16_t xacc[D / 32];     // fc2 accumulators: output tile ot (32 columns) x this lane's row; start from the residual rows
+    f32x16_t xacc[D / 32];     // fc2 accumulators: output tile ot (32 columns) x this lane's row
     f32x16_t ga, gb = {}, bias_c;     // two fc1 tiles: one being accumulated, one being activated
     s16x8_t gf0[2] = {}, gf1[2] = {};  // two activated tiles (fc2's B operands): one being packed, one being consumed
     // bias tile of hidden unit u: register r of lane half h = hidden 32 u + (r & 3) + 8 (r >> 2) + 4 h
@@ -292,55 +280,87 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
       }
     };
     // The unit sequence (= the order of the packed images): fc1 runs two hidden units ahead of fc2, and the activation of the
-    // unit in between is spread over both units of a pair.  Beside the first three units (fc1 only) the residual rows are
-    // loaded into the fc2 accumulators, beside the last but one (fc2 only) the next tile's h: what is left between two tiles
-    // is the LayerNorm arithmetic and the stores.  vmcnt per unit: 18 + what the three units before it issued on top
-    // (unit 0 .. 3: the 96 stores of the previous tile's epilogue / 16 loads per unit, capped at 63).
+    // unit in between is spread over both units of a pair.  The first four units wait for nothing but their barriers: their
+    // images (and the one the fourth reads ahead) landed before the previous tile's epilogue / the loop, which gives that
+    // epilogue's stores four units to drain before a counted wait stands behind them.
     load_bias(0);
-    mlp_unit<DT, true, 0, 63, 0>(st, base, wf, hf, xacc, ga, bias_c, gb, gf0, gf0, io);                  // fc1(0)
+    mlp_unit<DT, true, 0, -1>(st, base, wf, hf, xacc, ga, bias_c, gb, gf0, gf0);                     // fc1(0)
     MLP_STAMP(1);
     load_bias(1);
-    mlp_unit<DT, true, 3, 63, 1>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf0, io);                  // fc1(1) | gelu(0) -> gf0
+    mlp_unit<DT, true, 3, -1>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf0);                     // fc1(1) | gelu(0) -> gf0
     load_bias(2);
-    mlp_unit<DT, true, 1, 63, 2>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1, io);                  // fc1(2) | gelu(1), values 0 .. 7
-    mlp_unit<DT, false, 2, 63>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0, io);                    // fc2(0) | gelu(1), values 8 .. 15
+    mlp_unit<DT, true, 1, -1>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1);                     // fc1(2) | gelu(1), values 0 .. 7
+    mlp_unit<DT, false, 2, -1, true>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0);               // fc2(0) | gelu(1), values 8 .. 15
     load_bias(3);
-    mlp_unit<DT, true, 1, 18 + 32>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf0, io);                // fc1(3) | gelu(2)
-    mlp_unit<DT, false, 2, 18 + 16>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf1, io);               // fc2(1) | gelu(2)
+    mlp_unit<DT, true, 1>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf0);                         // fc1(3) | gelu(2)
+    mlp_unit<DT, false, 2>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf1);                        // fc2(1) | gelu(2)
     MLP_STAMP(2);
     for (int u = 2; u < UNITS - 2; u += 2) {
       load_bias(u + 2);
-      mlp_unit<DT, true, 1>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1, io);                       // fc1(u + 2) | gelu(u + 1)
-      mlp_unit<DT, false, 2>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0, io);                      // fc2(u)     | gelu(u + 1)
+      mlp_unit<DT, true, 1>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1);                       // fc1(u + 2) | gelu(u + 1)
+      mlp_unit<DT, false, 2>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0);                      // fc2(u)     | gelu(u + 1)
       load_bias(u + 3);
-      mlp_unit<DT, true, 1>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf0, io);                       // fc1(u + 3) | gelu(u + 2)
-      mlp_unit<DT, false, 2>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf1, io);                      // fc2(u + 1) | gelu(u + 2)
+      mlp_unit<DT, true, 1>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf0);                       // fc1(u + 3) | gelu(u + 2)
+      mlp_unit<DT, false, 2>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf1);                      // fc2(u + 1) | gelu(u + 2)
     }
     MLP_STAMP(3);
-    mlp_unit<DT, false, 3, 18, -1, MLP_HP == 1>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0, io);   // fc2(46) | gelu(47) -> gf1
-    mlp_unit<DT, false, 0, MLP_HP == 1 ? 18 + 24 : 18, -1, false, true>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1, io);               // fc2(47)
+    mlp_unit<DT, false, 3>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0);                          // fc2(46) | gelu(47) -> gf1
+    mlp_unit<DT, false, 0, 3 * PIECES, false, true>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1);   // fc2(47)
 
     // ---- epilogue: x[row][col .. col + 3] = acc + b2, lane owns row m, columns 32 ot + 8 g + 4 h + {0 .. 3}; then the
     //      LayerNorm of the new row from the same registers (three passes, one output tile at a time: the compiler otherwise
     //      keeps all 192 values in flight twice and spills the next tile's h) ----
     MLP_STAMP(4);
-    if (MLP_HP == 2) {         // the next tile's h fragments: in flight while the LayerNorm below is computed
+    // Everything this wave has requested has landed (the five images ahead: the first four units of the next tile wait for
+    // nothing but their barriers, so the stores below have until the fifth to drain -- vmcnt counts in order), and everybody
+    // has left the last image's slot: a quarter of it is this wave's staging space until the next unit refills it.
+    // A lane owns a row: written as they stand, the accumulators would go out in 32-byte runs (two lanes per row), which a
+    // CU's store path takes at about 7 bytes per cycle.  So every output tile takes a turn through LDS: the residual rows
+    // come in eight lanes per row (128-byte runs, three tiles requested ahead), are read back a row per lane, and the sum
+    // goes the other way.  Row stride 144 bytes (36 banks).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int ln = lane;             // (opaque: the addresses below are recomputed here, a few VALU per tile, not kept in -- spilled --
+    asm volatile("" : "+v"(ln));   //  registers across the units; the constants added to them stay immediate offsets)
+    const unsigned stg = (unsigned)(size_t)LDS_PTR(smem) + (st.slot == 0 ? NSLOT - 1 : st.slot - 1) * UB + wave * STG_BYTES;
+    const unsigned stg_wr = stg + (ln & 31) * STG_ROW + 16 * (ln >> 5);     // row per lane: + 32 g
+    const unsigned stg_wh = stg + (ln & 31) * STG_ROW + 8 * (ln >> 5);      // (16-bit rows: + 64 o2 + 16 g)
+    const unsigned stg_rd = stg + (ln >> 3) * STG_ROW + (ln & 7) * 16;      // eight lanes per row: + 8 i rows
+    const int xo = (wave * 32 + (ln >> 3)) * (D * 4) + (ln & 7) * 16;       // x: row 8 i + lane / 8, columns 32 ot + 4 (lane % 8) ..
+    const int ho = (wave * 32 + (ln >> 3)) * (D * 2) + (ln & 7) * 16;       // h: the same rows, columns 64 op + 8 (lane % 8) ..
+    // the next tile's h fragments: in flight during the whole epilogue
+    const int hfo = (wave * 32 + (ln & 31)) * (D * 2) + 16 * (ln >> 5);
 #pragma unroll
-      for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(io.h_next, io.hoff, 32 * s, 0));
-    }
+    for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(io.h_next, hfo, 32 * s, 0));
+    constexpr int XA = 3;      // residual tiles requested ahead (deeper: no faster, measured)
+    u32x4_t xi[XA][4];
+    auto x_request = [&](int ot) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xi[ot % XA][i] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo + ot * 128, i * 8 * (D * 4), 0);
+    };
+#pragma unroll
+    for (int ot = 0; ot < XA; ++ot) x_request(ot);
     float s = 0.f;
 #pragma unroll
     for (int ot = 0; ot < D / 32; ++ot) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = 32 * ot + 8 * g;
-        const float4 bv = cst4(HID + col);
-        u32x4_t v;
-        xacc[ot][4 * g + 0] += bv.x; xacc[ot][4 * g + 1] += bv.y; xacc[ot][4 * g + 2] += bv.z; xacc[ot][4 * g + 3] += bv.w;
+      for (int i = 0; i < 4; ++i) *(lds_w4_ptr)(stg_rd + i * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[ot % XA][i]);
+      if (ot + XA < D / 32) x_request(ot + XA);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(xacc[ot][4 * g + e]);
-        __builtin_amdgcn_raw_buffer_store_b128(v, io.x, io.xoff, col * 4, 0);
-        s += (xacc[ot][4 * g + 0] + xacc[ot][4 * g + 1]) + (xacc[ot][4 * g + 2] + xacc[ot][4 * g + 3]);
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = cst4(HID + 32 * ot + 8 * g);
+        const f32x4_t xv = *(lds_f4_ptr)(stg_wr + 32 * g);
+        f32x4_t v;
+        v[0] = xv[0] + (xacc[ot][4 * g + 0] + bv.x); v[1] = xv[1] + (xacc[ot][4 * g + 1] + bv.y);
+        v[2] = xv[2] + (xacc[ot][4 * g + 2] + bv.z); v[3] = xv[3] + (xacc[ot][4 * g + 3] + bv.w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xacc[ot][4 * g + e] = v[e];
+        *(lds_w4_ptr)(stg_wr + 32 * g) = v;
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4_t v = *(lds_f4_ptr)(stg_rd + i * 8 * STG_ROW);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.x, xo + ot * 128, i * 8 * (D * 4), 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -365,16 +385,25 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
       MLP_STAMP(6);
       const float rstd = 1.0f / sqrtf(q / (float)D + ln_eps);
 #pragma unroll
-      for (int ot = 0; ot < D / 32; ++ot) {
+      for (int op = 0; op < D / 64; ++op) {            // two output tiles = 64 columns = 128 bytes of a 16-bit row
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = 32 * ot + 8 * g;
-          const float4 gg = cst4(HID + D + col);
-          const float4 bb = cst4(HID + 2 * D + col);
-          u32x2_t pk;
-          pk[0] = pack2_h16<DT>((xacc[ot][4 * g + 0] - mean) * rstd * gg.x + bb.x, (xacc[ot][4 * g + 1] - mean) * rstd * gg.y + bb.y);
-          pk[1] = pack2_h16<DT>((xacc[ot][4 * g + 2] - mean) * rstd * gg.z + bb.z, (xacc[ot][4 * g + 3] - mean) * rstd * gg.w + bb.w);
-          __builtin_amdgcn_raw_buffer_store_b64(pk, io.h_out, io.hooff, col * 2, 0);
+        for (int o2 = 0; o2 < 2; ++o2) {
+          const int ot = 2 * op + o2;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int col = 32 * ot + 8 * g;
+            const float4 gg = cst4(HID + D + col);
+            const float4 bb = cst4(HID + 2 * D + col);
+            u32x2_t pk;
+            pk[0] = pack2_h16<DT>((xacc[ot][4 * g + 0] - mean) * rstd * gg.x + bb.x, (xacc[ot][4 * g + 1] - mean) * rstd * gg.y + bb.y);
+            pk[1] = pack2_h16<DT>((xacc[ot][4 * g + 2] - mean) * rstd * gg.z + bb.z, (xacc[ot][4 * g + 3] - mean) * rstd * gg.w + bb.w);
+            *(lds_w2_ptr)(stg_wh + 64 * o2 + 16 * g) = pk;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4_t v = *(lds_f4_ptr)(stg_rd + i * 8 * STG_ROW);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.h_out, ho + op * 128, i * 8 * (D * 2), 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -414,5 +443,6 @@ extern "C" int vittf_mlp_fused(const void* h, const void* w_packed, const float*
   else if (dtype == VITTF_FP16) MLP_LAUNCH(VITTF_FP16);
   else return VITTF_ERR_INVALID_ARG;
 #undef MLP_LAUNCH
+  vittf_note_kernel(VITTF_KERNEL_MLP, "mlp_kernel");
   return vittf_check_launch();
 }
