@@ -81,6 +81,10 @@ typedef struct vittf_vit_weights {
                             fused MLP kernel consumes (vittf_mlp_fused; packing: vit-tf_amd/weights.py pack_mlp_weights);
                             when non-NULL and D == 384 the engine runs fc1 -> GELU -> fc2 -> residual -> next LayerNorm as
                             one launch instead of two GEMMs */
+  const void*  tail_packed; /* h16 [L][108][12288] or NULL: proj_w, fc1_w and fc2_w of every block as the stream of the
+                            block-tail kernel (vittf_block_tail; weights.py pack_block_tail_weights); when non-NULL and
+                            D == 384 the engine runs everything behind the attention of a block -- proj, residual, norm2,
+                            MLP, residual, the next block's norm1 -- as one launch (takes precedence over mlp_packed) */
   const float* ln1_g;    /* [L][D] */
   const float* ln1_b;    /* [L][D] */
   const float* ln2_g;    /* [L][D] */
@@ -201,6 +205,18 @@ int vittf_ln_gemm(const float* x, const float* ln_g, const float* ln_b, float ln
  * summation order of fc2 (the hidden activation is identical: both round it once to h16). */
 int vittf_mlp_fused(const void* h, const void* w_packed, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
                     int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* stream);
+
+/* Everything behind the attention of one block for D == 384, in one launch:
+ *   x' = x + attn_out . Wp^T + proj_b ;  x_new = x' + fc2(gelu_erf(fc1(LayerNorm(x'; ln2)) + b1)) + b2 ;  x := x_new ;
+ *   h_out = LayerNorm(x_new; ln_g, ln_b)  (the next block's norm1; optional as in vittf_mlp_fused).
+ * Replaces Attention.proj + the two residual adds + norm2 + Mlp.forward of the upstream DINO block (reached through
+ * model(...), infer.py:177).  attn_out: h16 [rows][D] (vittf_attention's output); w_packed: h16 [108][12288], one block of
+ * vittf_vit_weights.tail_packed.  The fp32 residual rows are read once and written once, and neither x' nor norm2's output
+ * nor the hidden activation reaches HBM.  Same result as vittf_gemm_residual_ln (proj) + vittf_mlp_fused up to fp32
+ * summation order. */
+int vittf_block_tail(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g, const float* ln2_b,
+                     const float* b1, const float* b2, float* x, int64_t rows, int32_t d, int32_t dtype, const float* ln_g,
+                     const float* ln_b, float ln_eps, void* h_out, void* stream);
 
 /* Multi-head self-attention over `batch` independent sequences of `tokens` rows.
  * qkv h16 [batch*tokens][3D] with columns [q | k | v], heads of 64 concatenated inside each third

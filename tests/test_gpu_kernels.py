@@ -157,6 +157,61 @@ def test_mlp_fused(gpu, dt, rows, with_ln):
                                None, None, 1e-6, None, _lib.stream_ptr()) == -1
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows', [1, 130, 4097, 128 * 300 + 77])
+def test_block_tail(gpu, dt, rows):
+    """proj + residual + norm2 + MLP + residual + the next norm1 in one launch (vittf_block_tail) against fp64 (norm2's
+    output and the hidden activation rounded once to the 16-bit type, as every path does) and against the launches it
+    replaces (vittf_gemm_residual_ln for proj, vittf_mlp_fused)."""
+    lib = _lib.load()
+    d = 384
+    g = gen(rows + 5)
+    a = torch.randn(rows, d, generator=g).to(TDT[dt])
+    wp = (torch.randn(d, d, generator=g) / d ** 0.5).to(TDT[dt])
+    bp = 0.3 * torch.randn(d, generator=g)
+    w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt])
+    b1 = 0.3 * torch.randn(4 * d, generator=g)
+    w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
+    b2 = 0.3 * torch.randn(d, generator=g)
+    g2, e2 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    g1, e1 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    x0 = torch.randn(rows + 2, d, generator=g) * 3
+    ad, wpd, bpd, w1d, b1d, w2d, b2d, g2d, e2d, g1d, e1d = (t.to(gpu) for t in (a, wp, bp, w1, b1, w2, b2, g2, e2, g1, e1))
+    # fp64 reference
+    x1 = x0[:rows].to(gpu).double() + ad.double() @ wpd.double().t() + bpd.double()
+    hn = F.layer_norm(x1, (d,), g2d.double(), e2d.double(), 1e-6).to(TDT[dt]).double()
+    hid = F.gelu(hn @ w1d.double().t() + b1d.double()).to(TDT[dt]).double()
+    ref = (x1 + hid @ w2d.double().t() + b2d.double()).cpu()
+    wpk = vt.weights.pack_block_tail_weights(wpd[None], w1d[None], w2d[None])[0].contiguous()
+    assert wpk.shape == (108, 12288)
+    xd = x0.to(gpu)
+    hout = torch.full((rows + 2, d), 7.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
+                                    _lib.ptr(xd), rows, d, _lib.DTYPES[dt], _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(hout),
+                                    _lib.stream_ptr()))
+    got = xd.cpu().double()
+    assert torch.equal(got[rows:], x0[rows:].double()), 'wrote past the last row'
+    assert (hout[rows:].float() == 7.0).all(), 'wrote past the last row of h'
+    # a norm2 output / hidden unit on a rounding boundary may round the other way than in fp64: compare in norm
+    assert rel_fro(got[:rows] - x0[:rows].double(), ref - x0[:rows].double()) <= EPS[dt] / 2
+    assert ((got[:rows] - ref).abs() <= 6 * EPS[dt] + 1e-4).all()
+    want = F.layer_norm(got[:rows], (d,), g1.double(), e1.double(), 1e-6)
+    assert ((hout[:rows].cpu().double() - want).abs() <= 2 * EPS[dt] * (1 + want.abs())).all()
+    # the launches it replaces
+    x2 = x0.to(gpu)
+    h2 = torch.zeros(rows, d, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_gemm_residual_ln(_lib.ptr(ad), _lib.ptr(wpd), _lib.ptr(bpd), _lib.ptr(x2), rows, d, d, _lib.DTYPES[dt],
+                                          _lib.ptr(g2d), _lib.ptr(e2d), 1e-6, _lib.ptr(h2), _lib.stream_ptr()))
+    mpk = vt.weights.pack_mlp_weights(w1d[None], w2d[None])[0].contiguous()
+    h3 = torch.zeros(rows, d, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_mlp_fused(_lib.ptr(h2), _lib.ptr(mpk), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(x2), rows, d, _lib.DTYPES[dt],
+                                   _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h3), _lib.stream_ptr()))
+    assert rel_fro(xd[:rows].double() - x0[:rows].to(gpu).double(), x2[:rows].double() - x0[:rows].to(gpu).double()) <= EPS[dt] / 2
+    assert rel_fro(hout[:rows].float(), h3.float()) <= 2 * EPS[dt]
+    assert lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
+                                _lib.ptr(xd), rows, 768, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.stream_ptr()) == -1
+
+
 # ------------------------------------------------------------------------------------------ attention
 QSCALE = 0.125 * 1.4426950408889634      # log2(e) / 8, what VITTF_EPI_BIAS_QKV folds into q
 

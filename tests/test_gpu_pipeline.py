@@ -388,8 +388,9 @@ def test_fos128_long_sequence(gpu):
 
 
 def test_optional_paths_agree_with_default(gpu):
-    """The engine's alternative paths (two-GEMM MLP instead of the fused kernel, several stream lanes) compute the same
-    feature volume as the default path: stream lanes bit for bit, the two MLP paths up to fp32 summation order."""
+    """The engine's alternative paths (the fused MLP kernel behind a projection GEMM, or three GEMMs, instead of the
+    block-tail kernel; several stream lanes) compute the same feature volume as the default path: stream lanes bit for
+    bit, the others up to fp32 summation order and 16-bit rounding boundaries."""
     arch = (384, 2, 6, 8)
     sd = vt.synthetic_state_dict(arch, 9)
     vol = (torch.rand((16, 24, 40), generator=torch.Generator().manual_seed(4)) * 2 - 1).half().float()
@@ -401,12 +402,14 @@ def test_optional_paths_agree_with_default(gpu):
     finally:
         vt.extract.STREAM_LANES = old
     assert torch.equal(base, lanes)
-    fused = vt.feature_volume(vol, vt.HipViT(sd, arch, 'bf16', fused_mlp=True), 2, 'all', engine_batch=4).cpu()
-    split = vt.feature_volume(vol, vt.HipViT(sd, arch, 'bf16', fused_mlp=False), 2, 'all', engine_batch=4).cpu()
-    assert rel_fro(fused, split) < 1e-3
+    tail = vt.feature_volume(vol, vt.HipViT(sd, arch, 'bf16', fused_tail=True), 2, 'all', engine_batch=4).cpu()
+    fused = vt.feature_volume(vol, vt.HipViT(sd, arch, 'bf16', fused_mlp=True, fused_tail=False), 2, 'all', engine_batch=4).cpu()
+    split = vt.feature_volume(vol, vt.HipViT(sd, arch, 'bf16', fused_mlp=False, fused_tail=False), 2, 'all', engine_batch=4).cpu()
+    assert torch.equal(base, tail)                                        # the default IS the block-tail kernel
+    assert rel_fro(fused, split) < 1e-3 and rel_fro(tail, split) < 1e-3
     oracle = dino_vit.build_vit(arch, sd)
     ref = ofv.feature_volume(vol, oracle, 8, 2, 'all', batch_size=8)
-    assert rel_fro(fused, ref) <= TOL['bf16'][0] and rel_fro(split, ref) <= TOL['bf16'][0]
+    assert rel_fro(tail, ref) <= TOL['bf16'][0] and rel_fro(fused, ref) <= TOL['bf16'][0] and rel_fro(split, ref) <= TOL['bf16'][0]
 
 
 def test_evaluate_similarities_entry(gpu, tmp_path):

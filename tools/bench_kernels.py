@@ -154,6 +154,21 @@ def main():
                                                             _lib.DTYPES[dt], _lib.ptr(lg), _lib.ptr(lb), 1e-6, _lib.ptr(hn), _lib.stream_ptr())))
         fl = 4 * rows * d * 4 * d
         print(f'fused mlp + ln [{rows}x{d}]: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({ms * 32 / batch:.4f} ms per 32 slices)')
+    if 'tail' in what:
+        aa = torch.randn(rows, d, generator=g).to(TDT[dt]).to(dev)
+        wp = (torch.randn(d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(dev)
+        w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(dev)
+        w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt]).to(dev)
+        tpk = vt.weights.pack_block_tail_weights(wp[None], w1[None], w2[None])[0].contiguous()
+        bp = torch.randn(d, generator=g).to(dev); b1 = torch.randn(4 * d, generator=g).to(dev); b2 = torch.randn(d, generator=g).to(dev)
+        x = torch.zeros(rows, d, device=dev)
+        lg = torch.ones(d, device=dev); lb = torch.zeros(d, device=dev)
+        hn = torch.empty(rows, d, dtype=TDT[dt], device=dev)
+        ms = timeit(lambda: _lib.check(lib.vittf_block_tail(_lib.ptr(aa), _lib.ptr(tpk), _lib.ptr(bp), _lib.ptr(lg), _lib.ptr(lb), _lib.ptr(b1),
+                                                             _lib.ptr(b2), _lib.ptr(x), rows, d, _lib.DTYPES[dt], _lib.ptr(lg), _lib.ptr(lb), 1e-6,
+                                                             _lib.ptr(hn), _lib.stream_ptr())))
+        fl = 18 * rows * d * d
+        print(f'block tail (proj + ln + mlp + ln) [{rows}x{d}]: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({ms * 32 / batch:.4f} ms per 32 slices)')
     if 'ln' in what:
         x = torch.randn(rows, d, generator=g).to(dev)
         w = torch.ones(d, device=dev); b = torch.zeros(d, device=dev)

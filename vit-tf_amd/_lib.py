@@ -22,7 +22,7 @@ class VitConfig(C.Structure):
 
 class VitWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        'pe_w_t', 'pe_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'mlp_packed',
+        'pe_w_t', 'pe_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'mlp_packed', 'tail_packed',
         'ln1_g', 'ln1_b', 'ln2_g', 'ln2_b')]
 
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     'vittf_gemm_residual_ln': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp]),
     'vittf_ln_gemm': (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     'vittf_mlp_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp]),
+    'vittf_block_tail': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp]),
     'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vittf_attention_rescale_count': (_i64, [_i32]),
     'vittf_attention_fp8_workspace_bytes': (_sz, [_i32, _i32, _i32]),

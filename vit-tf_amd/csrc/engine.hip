@@ -131,7 +131,7 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   // Parity-green, but the fp32 rows are then fetched once per 384-column panel (3-4 x 201 MB instead of 3-4 x 100 MB of
   // 16-bit rows), which costs more than the LayerNorm launches: 1690 against 1720 slices/s on the 256^3 workload.
   static const bool ln_fused_env = [] { const char* e = getenv("VITTF_LN_FUSED"); return e && atoi(e) != 0; }();
-  const bool ln_fused = ln_fused_env && d == 384 && !(w->mlp_packed);
+  const bool ln_fused = ln_fused_env && d == 384 && !(w->mlp_packed) && !(w->tail_packed);
   // Default (D = 384 / 768): every LayerNorm but the first rides on the epilogue of the residual GEMM in front of it
   // (vittf_gemm_residual_ln: proj -> norm2, fc2 -> the next block's norm1); VITTF_RESIDUAL_LN=0 keeps them separate.
   static const bool res_ln_env = [] { const char* e = getenv("VITTF_RESIDUAL_LN"); return !e || atoi(e) != 0; }();
@@ -168,6 +168,17 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
       else
         rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, pre, stream); }
     if (rc) return rc;
+    if (d == 384 && w->tail_packed && res_ln) {
+      // everything behind the attention -- proj, residual, norm2, fc1, GELU, fc2, residual, the next block's norm1 -- in one
+      // launch: the residual rows are read once and written once, nothing else of it reaches HBM
+      ProfScope ps(VITTF_KERNEL_MLP, stream);
+      rc = vittf_block_tail(O, (const char*)w->tail_packed + (size_t)l * 108 * 12288 * esz, w->proj_b + (size_t)l * d,
+                            w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, w->fc1_b + (size_t)l * 4 * d,
+                            w->fc2_b + (size_t)l * d, X, rows, d, dt, w->ln1_g + (size_t)(l + 1) * d,
+                            w->ln1_b + (size_t)(l + 1) * d, cfg->ln_eps, H, stream);
+      if (rc) return rc;
+      continue;
+    }
     { ProfScope ps(VITTF_KERNEL_GEMM_PROJ, stream);
       if (res_ln)
         rc = vittf_gemm_residual_ln(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d,

@@ -39,14 +39,21 @@ namespace {
 
 constexpr int D = 384, HID = 4 * D;
 constexpr int UNITS = HID / 32;            // 48 hidden units of 32
-constexpr int NSEQ = 2 * UNITS;            // streamed images per row tile: W1(0), W1(1), W1(2), W2(0), W1(3), W2(1), .., W1(47), W2(45), W2(46), W2(47)
+// streamed images per row tile: [Wp(0) .. Wp(11),] W1(0), W1(1), W1(2), W2(0), W1(3), W2(1), .., W1(47), W2(45), W2(46), W2(47)
 constexpr int UB = 24576;                  // bytes of one image: 6 sub-images [32 rows][64 k] in the tile_off layout
-constexpr int NSLOT = 6, AHEAD = NSLOT - 1;
+constexpr int PUNITS = D / 32;             // block tail: 12 projection units in front (one image per output tile, K = 384)
+constexpr int NSLOT = 5, AHEAD = NSLOT - 1;
 constexpr int NF = 8;                      // fragment registers in flight
 constexpr int PIECES = UB / 1024 / 4;      // LDS-DMA pieces per wave and unit
-constexpr int CONST_OFF = NSLOT * UB;      // b1 [1536] | b2 [384] | gamma [384] | beta [384] as fp32 behind the ring
-constexpr int LDS_BYTES = CONST_OFF + (HID + 3 * D) * 4;
-constexpr int STG_ROW = 144, STG_BYTES = UB / 4;          // epilogue staging: 32 rows of 128 bytes + 16 per wave, in a quarter of a ring slot
+constexpr int WAIT0 = (AHEAD - 2) * PIECES;   // pieces of this wave that may be in flight when a unit starts (see mlp_unit)
+constexpr int STG_OFF = NSLOT * UB;        // staging behind the ring: a quarter per wave, 32 rows of 128 bytes + 16
+constexpr int STG_ROW = 144, STG_BYTES = UB / 4;
+constexpr int CONST_OFF = STG_OFF + UB;    // fp32 constants behind that, in floats:
+constexpr int C_B1 = 0, C_B2 = HID, C_G1 = HID + D, C_E1 = HID + 2 * D,       // b1 | b2 | gamma, beta of the LayerNorm behind the MLP
+              C_BP = HID + 3 * D, C_G2 = HID + 4 * D, C_E2 = HID + 5 * D,      // block tail: proj bias | gamma, beta of norm2
+              C_N = HID + 6 * D;
+constexpr int LDS_BYTES = CONST_OFF + C_N * 4;
+constexpr int XA = 3;                      // residual tiles (32 columns) requested ahead (deeper: no faster, measured)
 static_assert(32 * STG_ROW <= STG_BYTES, "staging");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 
@@ -60,7 +67,8 @@ struct TileIO {                // a row tile's activations: descriptors that end
 struct Stream {                // where the weight stream stands (wave-uniform)
   i32x4_t rsrc;                // descriptor over one layer's NSEQ packed images
   unsigned dma_dst;            // LDS byte address of this wave's first piece in slot 0
-  int g;                       // stream position of the unit being computed (0 .. NSEQ - 1, wraps with the row tiles)
+  int nseq;                    // images per row tile (96, or 108 with the projection in front)
+  int g;                       // stream position of the unit being computed (0 .. nseq - 1, wraps with the row tiles)
   int slot;                    // its ring slot
 };
 
@@ -124,23 +132,83 @@ __device__ __forceinline__ float gelu_c(const Gelu3& s, float x) {
   return v;
 }
 
+// Start of a unit.  Its image was requested AHEAD units ago; of what this wave has issued since, only the pieces of the two
+// units behind the NEXT one may still be in flight: the next unit's image has landed too (its fragments are read from MFMA
+// 16 on).  vmcnt counts every load and store of the wave, in order: WAITN = those 12 pieces + whatever else the wave has
+// issued in its last two units.  The barrier also says that everybody is done with the slot of the unit before this one,
+// which is refilled during this one.  WAITN < 0: no counted wait (the units right behind a drain, see the kernel).
+template <int WAITN>
+__device__ __forceinline__ void unit_wait() {
+  static_assert(WAITN <= 63 && (WAITN < 0 || WAITN >= WAIT0), "vmcnt");
+  if constexpr (WAITN < 0) asm volatile("s_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(V_NO_DMA ? 0 : WAITN) : "memory");
+}
+
+// what every unit does behind MFMA j besides its own work: turn the fragment bases to the next image at j == 16, refill the
+// fragment register the MFMA has just used, and behind every fourth MFMA request one piece of the image AHEAD
+template <bool LAST = false>
+__device__ __forceinline__ void stream_gap(const Stream& st, unsigned (&base)[4], s16x8_t (&wf)[NF], int j, int g_next, int slot_free) {
+  if (j == 24 - NF) {                          // from here on the refills read the next unit's image
+    const int d_ = st.slot == NSLOT - 1 ? -(NSLOT - 1) * UB : UB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) base[i] += d_;
+  }
+  if (!V_NO_REFILL && !(LAST && j >= 24 - NF)) wf[j % NF] = ld_frag(base, (j + NF) % 24);   // (a tile's last unit: see the kernel)
+  if ((j & 3) == 3 && !V_NO_DMA) {
+    const unsigned dst = st.dma_dst + slot_free * UB + (j >> 2) * 4096;
+    const int src = g_next * UB + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 1024 + (j >> 2) * 4096;
+    if (V_M0_KEEP) lds_dma16(st.rsrc, dst, (int)((threadIdx.x & 63) * 16), src);
+    else lds_dma16_keep(st.rsrc, dst, (int)((threadIdx.x & 63) * 16), src);
+  }
+}
+
+// One projection unit of the block tail = 24 MFMAs: xacc[OT] = Wp rows 32 OT .. + 31 . a^T (+ the bias tile as initial value).
+// In its gaps the residual columns of the tile BEFORE it (whose product is complete) are folded in: the chunk requested
+// three units ago goes through the staging rows (written eight lanes per row as it was loaded, read back a row per lane)
+// and is added to xacc[OT - 1]; the freed registers then request the chunk three tiles further on (REQ).
+template <int DT, int OT, int WAITN, bool REQ, bool LAST>
+__device__ __forceinline__ void proj_unit(Stream& st, unsigned (&base)[4], s16x8_t (&wf)[NF], const s16x8_t (&af)[D / 16],
+                                          f32x16_t (&xacc)[D / 32], const f32x16_t& bias_c, u32x4_t (&xi)[XA][4],
+                                          const TileIO& io, int xo, unsigned stg_rd, unsigned stg_wr) {
+  unit_wait<WAITN>();
+  const int g_next = st.g + AHEAD < st.nseq ? st.g + AHEAD : st.g + AHEAD - st.nseq;
+  const int slot_free = st.slot == 0 ? NSLOT - 1 : st.slot - 1;
+  [[maybe_unused]] f32x4_t xv[4];
+#pragma unroll
+  for (int j = 0; j < 24; ++j) {
+    xacc[OT] = mfma32<DT>(wf[j % NF], af[j], j == 0 ? bias_c : xacc[OT]);
+    stream_gap<LAST>(st, base, wf, j, g_next, slot_free);
+    if constexpr (OT > 0) {
+      if (j < 4) {
+        *(lds_w4_ptr)(stg_rd + j * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[(OT - 1) % XA][j]);
+      } else if (j >= 6 && j < 10) {
+        xv[j - 6] = *(lds_f4_ptr)(stg_wr + 32 * (j - 6));
+      } else if (j >= 10 && j < 18) {
+        const int r = 2 * (j - 10);
+        xacc[OT - 1][r] += xv[r >> 2][r & 3];
+        xacc[OT - 1][r + 1] += xv[r >> 2][(r & 3) + 1];
+      }
+      if constexpr (REQ)
+        if (j >= 18 && j < 22)
+          xi[(OT - 1) % XA][j - 18] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo + (OT - 1 + XA) * 128, (j - 18) * 8 * (D * 4), 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  st.g = st.g + 1 == st.nseq ? 0 : st.g + 1;
+  st.slot = st.slot + 1 == NSLOT ? 0 : st.slot + 1;
+}
+
 // One unit of the stream = 24 MFMAs.  FC1: gacc = W1u . h^T (+ the bias tile as initial value); FC2: xacc[ot] += W2u . gf_in.
 // GH: which part of the activation of the fc1 tile gprev runs in this unit's gaps -- 0 none, 1 values 0 .. 7 -> gf_out[0],
 // 2 values 8 .. 15 -> gf_out[1] (one value per three gaps, a third of it in each), 3 all sixteen (first / last units of a tile).
 // WAITN < 0: no counted wait (see the kernel); ZI: a tile's first fc2 unit, its accumulators start from zero; LAST: a tile's
 // last unit reads no fragments ahead.
-template <int DT, bool FC1, int GH, int WAITN = 3 * PIECES, bool ZI = false, bool LAST = false>
+template <int DT, bool FC1, int GH, int WAITN = WAIT0, bool ZI = false, bool LAST = false>
 __device__ __forceinline__ void mlp_unit(Stream& st, unsigned (&base)[4], s16x8_t (&wf)[NF], s16x8_t (&hf)[D / 16],
                                          f32x16_t (&xacc)[D / 32], f32x16_t& gacc, const f32x16_t& bias_c,
                                          const f32x16_t& gprev, s16x8_t (&gf_out)[2], const s16x8_t (&gf_in)[2]) {
-  // the unit's image was requested AHEAD units ago; of what this wave issued since only the pieces of the three units behind
-  // the NEXT one may still be in flight: the next unit's image has landed too (its fragments are read from MFMA 16 on).
-  // (vmcnt counts every load and store of the wave, in order: the units issue nothing but these pieces.)  The barrier also
-  // says that everybody is done with the slot of the unit before this one, which is refilled below.
-  static_assert(WAITN < 0 || WAITN == 3 * PIECES, "vmcnt");
-  if constexpr (WAITN < 0) asm volatile("s_barrier" ::: "memory");      // (the tile's first units: everything landed before the epilogue)
-  else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(V_NO_DMA ? 0 : WAITN) : "memory");
-  const int g_next = st.g + AHEAD < NSEQ ? st.g + AHEAD : st.g + AHEAD - NSEQ;       // (the stream wraps: the next row tile)
+  unit_wait<WAITN>();
+  const int g_next = st.g + AHEAD < st.nseq ? st.g + AHEAD : st.g + AHEAD - st.nseq;       // (the stream wraps: the next row tile)
   const int slot_free = st.slot == 0 ? NSLOT - 1 : st.slot - 1;
   u32x4_t pk0 = {}, pk1 = {};
   float vprev = 0.f;
@@ -149,18 +217,7 @@ __device__ __forceinline__ void mlp_unit(Stream& st, unsigned (&base)[4], s16x8_
   for (int j = 0; j < 24; ++j) {
     if constexpr (FC1) gacc = mfma32<DT>(wf[j % NF], hf[j], j == 0 ? bias_c : gacc);
     else xacc[j >> 1] = mfma32<DT>(wf[j % NF], gf_in[j & 1], ZI && !(j & 1) ? f32x16_t{} : xacc[j >> 1]);
-    if (j == 24 - NF) {                        // from here on the refills read the next unit's image
-      const int d_ = st.slot == NSLOT - 1 ? -(NSLOT - 1) * UB : UB;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) base[i] += d_;
-    }
-    if (!V_NO_REFILL && !(LAST && j >= 24 - NF)) wf[j % NF] = ld_frag(base, (j + NF) % 24);   // (a tile's last unit: see the kernel)
-    if ((j & 3) == 3 && !V_NO_DMA) {           // one LDS-DMA piece of the unit AHEAD behind every fourth MFMA
-      const unsigned dst = st.dma_dst + slot_free * UB + (j >> 2) * 4096;
-      const int src = g_next * UB + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 1024 + (j >> 2) * 4096;
-      if (V_M0_KEEP) lds_dma16(st.rsrc, dst, (int)((threadIdx.x & 63) * 16), src);
-      else lds_dma16_keep(st.rsrc, dst, (int)((threadIdx.x & 63) * 16), src);
-    }
+    stream_gap<LAST>(st, base, wf, j, g_next, slot_free);
     if constexpr (GH == 1 || GH == 2) {
       const int r = (GH == 2 ? 8 : 0) + j / 3;
       if (V_NO_GELU) {
@@ -198,12 +255,15 @@ __device__ __forceinline__ void mlp_unit(Stream& st, unsigned (&base)[4], s16x8_
   }
   if constexpr (GH == 1 || GH == 3) gf_out[0] = __builtin_bit_cast(s16x8_t, pk0);
   if constexpr (GH == 2 || GH == 3) gf_out[1] = __builtin_bit_cast(s16x8_t, pk1);
-  st.g = st.g + 1 == NSEQ ? 0 : st.g + 1;
+  st.g = st.g + 1 == st.nseq ? 0 : st.g + 1;
   st.slot = st.slot + 1 == NSLOT ? 0 : st.slot + 1;
 }
 
-template <int DT>
-__global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __restrict__ hbuf, const unsigned short* __restrict__ wpk,
+// TAIL: the block tail -- abuf holds the attention output, the projection (+ bias + residual) and norm2 run in front of the
+// MLP and the fp32 residual rows are read once and written once.  Otherwise abuf holds norm2's output (the MLP alone).
+template <int DT, bool TAIL>
+__global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __restrict__ abuf, const unsigned short* __restrict__ wpk,
+                                                     const float* __restrict__ bp, const float* __restrict__ g2, const float* __restrict__ e2,
                                                      const float* __restrict__ b1, const float* __restrict__ b2,
                                                      float* __restrict__ x, int64_t rows, const float* __restrict__ ln_g,
                                                      const float* __restrict__ ln_b, float ln_eps,
@@ -213,8 +273,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
   float* const cst = reinterpret_cast<float*>(smem + CONST_OFF);
-  for (int i = tid; i < HID + 3 * D; i += 256)
-    cst[i] = i < HID ? b1[i] : i < HID + D ? b2[i - HID] : i < HID + 2 * D ? (ln_g ? ln_g[i - HID - D] : 1.f) : (ln_b ? ln_b[i - HID - 2 * D] : 0.f);
+  for (int i = tid; i < C_N; i += 256) {
+    float v;
+    if (i < C_B2) v = b1[i];
+    else if (i < C_G1) v = b2[i - C_B2];
+    else if (i < C_E1) v = ln_g ? ln_g[i - C_G1] : 1.f;
+    else if (i < C_BP) v = ln_b ? ln_b[i - C_E1] : 0.f;
+    else if (i < C_G2) v = TAIL ? bp[i - C_BP] : 0.f;
+    else if (i < C_E2) v = TAIL ? g2[i - C_G2] : 1.f;
+    else v = TAIL ? e2[i - C_E2] : 0.f;
+    cst[i] = v;
+  }
 
   // this lane's view of the constants (half h reads 4 floats further on); opaque, so that every read below is this one
   // register + an immediate offset (hipcc otherwise keeps a separate address register per constant position and spills them)
@@ -222,7 +291,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
   asm volatile("" : "+v"(cl));
   auto cst4 = [&](int i) { const f32x4_t v = *(lds_f4_ptr)(cl + 4 * i); return make_float4(v[0], v[1], v[2], v[3]); };      // floats i .. i + 3 (+ 4 h) of the constants
   Stream st;
-  st.rsrc = lds_dma_rsrc(wpk, (unsigned)(NSEQ * UB));
+  st.nseq = TAIL ? PUNITS + 2 * UNITS : 2 * UNITS;
+  st.rsrc = lds_dma_rsrc(wpk, (unsigned)(st.nseq * UB));
   st.dma_dst = (unsigned)(size_t)LDS_PTR(smem) + wave * 1024;
   st.g = 0;
   st.slot = 0;
@@ -244,10 +314,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
                                              nrows * row_bytes, 0x00020000);
   };
   TileIO io;
-  // ---- this lane's h fragments (B operand) of the first tile: H[row][16 s + 8 h .. + 7], s = 0 .. 23 ----
+  // ---- this lane's activation fragments (B operand) of the first tile: A[row][16 s + 8 h .. + 7], s = 0 .. 23 ----
   s16x8_t hf[D / 16];
   {
-    const auto rs = tile_rsrc(hbuf, blockIdx.x, D * 2);
+    const auto rs = tile_rsrc(abuf, blockIdx.x, D * 2);
 #pragma unroll
     for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (wave * 32 + l31) * (D * 2) + 16 * h, 32 * s, 0));
   }
@@ -260,107 +330,197 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     ++tile_no;
     MLP_STAMP(0);
-    // the first fragments of the tile's first image (landed: the wait in front of the previous unit / above).  Every other
-    // unit reads its first eight fragments behind the last MFMAs of the unit before it; carried over the epilogue they
-    // would be spilled
+    // the first fragments of the tile's first image (landed: the drain in front of the previous epilogue / above).  Every
+    // other unit reads its first eight fragments behind the last MFMAs of the unit before it; carried over the epilogue
+    // they would be spilled
 #pragma unroll
     for (int f = 0; f < NF; ++f) wf[f] = ld_frag(base, f);
     io.x = tile_rsrc(x, tile, D * 4);
-    io.h_next = tile_rsrc(hbuf, (int64_t)tile + gridDim.x, D * 2);      // (no next tile: an empty descriptor)
+    io.h_next = tile_rsrc(abuf, (int64_t)tile + gridDim.x, D * 2);      // (no next tile: an empty descriptor)
     io.h_out = tile_rsrc(hout, tile, D * 2);
-    f32x16_t xacc[D / 32];     // fc2 accumulators: output tile ot (32 columns) x this lane's row
-    f32x16_t ga, gb = {}, bias_c;     // two fc1 tiles: one being accumulated, one being activated
-    s16x8_t gf0[2] = {}, gf1[2] = {};  // two activated tiles (fc2's B operands): one being packed, one being consumed
-    // bias tile of hidden unit u: register r of lane half h = hidden 32 u + (r & 3) + 8 (r >> 2) + 4 h
-    auto load_bias = [&](int u) {
+    int ln = lane;             // (opaque: the addresses below are recomputed per tile, a few VALU, not kept in -- spilled --
+    asm volatile("" : "+v"(ln));   //  registers across the units; the constants added to them stay immediate offsets)
+    const unsigned stg = (unsigned)(size_t)LDS_PTR(smem) + STG_OFF + wave * STG_BYTES;
+    const unsigned stg_wr = stg + (ln & 31) * STG_ROW + 16 * (ln >> 5);     // row per lane: + 32 g
+    const unsigned stg_rd = stg + (ln >> 3) * STG_ROW + (ln & 7) * 16;      // eight lanes per row: + 8 i rows
+    const int xo = (wave * 32 + (ln >> 3)) * (D * 4) + (ln & 7) * 16;       // x: row 8 i + lane / 8, columns 32 ot + 4 (lane % 8) ..
+    f32x16_t xacc[D / 32];     // output tile ot (32 columns) x this lane's row: the projection, then x', then fc2 on top of it
+    f32x16_t bias_c;
+    // bias tile of a unit: register r of lane half h = constant at + (r & 3) + 8 (r >> 2) + 4 h
+    auto load_bias = [&](int at) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 bv = cst4(32 * u + 8 * q);
+        const float4 bv = cst4(at + 8 * q);
         bias_c[4 * q + 0] = bv.x; bias_c[4 * q + 1] = bv.y; bias_c[4 * q + 2] = bv.z; bias_c[4 * q + 3] = bv.w;
       }
     };
-    // The unit sequence (= the order of the packed images): fc1 runs two hidden units ahead of fc2, and the activation of the
-    // unit in between is spread over both units of a pair.  The first four units wait for nothing but their barriers: their
-    // images (and the one the fourth reads ahead) landed before the previous tile's epilogue / the loop, which gives that
-    // epilogue's stores four units to drain before a counted wait stands behind them.
-    load_bias(0);
-    mlp_unit<DT, true, 0, -1>(st, base, wf, hf, xacc, ga, bias_c, gb, gf0, gf0);                     // fc1(0)
-    MLP_STAMP(1);
-    load_bias(1);
-    mlp_unit<DT, true, 3, -1>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf0);                     // fc1(1) | gelu(0) -> gf0
-    load_bias(2);
-    mlp_unit<DT, true, 1, -1>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1);                     // fc1(2) | gelu(1), values 0 .. 7
-    mlp_unit<DT, false, 2, -1, true>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0);               // fc2(0) | gelu(1), values 8 .. 15
-    load_bias(3);
+    if constexpr (TAIL) {
+      // ---- x' = x + proj(a) + bp, one output tile per unit; the residual chunks come in beside the units (three in flight).
+      //      The first three units wait for nothing but their barriers (their images landed before the drain); from then on
+      //      the counted wait also counts the four chunk loads per unit of the two units before. ----
+      u32x4_t xi[XA][4];
+#pragma unroll
+      for (int c = 0; c < XA; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xi[c][i] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo + c * 128, i * 8 * (D * 4), 0);
+#define PROJ_UNIT(OT, WAITN) load_bias(C_BP + 32 * (OT)); \
+      proj_unit<DT, OT, WAITN, ((OT) >= 1 && (OT) - 1 + XA < PUNITS), (OT) == PUNITS - 1>(st, base, wf, hf, xacc, bias_c, xi, io, xo, stg_rd, stg_wr)
+      PROJ_UNIT(0, -1); PROJ_UNIT(1, -1); PROJ_UNIT(2, -1);
+      PROJ_UNIT(3, WAIT0 + 8); PROJ_UNIT(4, WAIT0 + 8); PROJ_UNIT(5, WAIT0 + 8); PROJ_UNIT(6, WAIT0 + 8);
+      PROJ_UNIT(7, WAIT0 + 8); PROJ_UNIT(8, WAIT0 + 8); PROJ_UNIT(9, WAIT0 + 8); PROJ_UNIT(10, WAIT0 + 8);
+      PROJ_UNIT(11, WAIT0 + 4);
+#undef PROJ_UNIT
+      MLP_STAMP(1);
+      {                       // the last tile's chunk
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(lds_w4_ptr)(stg_rd + i * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[(PUNITS - 1) % XA][i]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t xv = *(lds_f4_ptr)(stg_wr + 32 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xacc[PUNITS - 1][4 * g + e] += xv[e];
+        }
+      }
+      // ---- norm2 of x' in registers -> the 24 B operands of fc1 (k step s, element e of lane half h = column
+      //      32 (s >> 1) + 16 (s & 1) + 8 (e >> 2) + 4 h + (e & 3): the host packs W1's input dim in that order) ----
+      float s = 0.f;
+#pragma unroll
+      for (int ot = 0; ot < D / 32; ++ot) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s += (xacc[ot][4 * g + 0] + xacc[ot][4 * g + 1]) + (xacc[ot][4 * g + 2] + xacc[ot][4 * g + 3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+        s = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+      const float mean = s / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int ot = 0; ot < D / 32; ++ot) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float dv = xacc[ot][r] - mean; q += dv * dv; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(q), __float_as_uint(q), false, false);
+        q = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+      const float rstd = 1.0f / sqrtf(q / (float)D + ln_eps);
+      float mean_p = mean;         // (opaque: recompute x - mean below; reusing the variance pass's 192 differences spills)
+      asm volatile("" : "+v"(mean_p));
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const int ot = ks >> 1;
+        u32x4_t pk;
+#pragma unroll
+        for (int g2_ = 0; g2_ < 2; ++g2_) {
+          const int g = 2 * (ks & 1) + g2_;
+          const float4 gg = cst4(C_G2 + 32 * ot + 8 * g);
+          const float4 bb = cst4(C_E2 + 32 * ot + 8 * g);
+          pk[2 * g2_ + 0] = pack2_h16<DT>((xacc[ot][4 * g + 0] - mean_p) * rstd * gg.x + bb.x, (xacc[ot][4 * g + 1] - mean_p) * rstd * gg.y + bb.y);
+          pk[2 * g2_ + 1] = pack2_h16<DT>((xacc[ot][4 * g + 2] - mean_p) * rstd * gg.z + bb.z, (xacc[ot][4 * g + 3] - mean_p) * rstd * gg.w + bb.w);
+        }
+        hf[ks] = __builtin_bit_cast(s16x8_t, pk);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // The MLP's unit sequence (= the order of the packed images): fc1 runs two hidden units ahead of fc2, and the activation
+    // of the unit in between is spread over both units of a pair.  Without the projection in front the first three units
+    // wait for nothing but their barriers: their images (and the one the third reads ahead) landed before the previous tile's
+    // epilogue / the loop, which gives that epilogue's stores three units to drain before a counted wait stands behind them.
+    f32x16_t ga, gb = {};              // two fc1 tiles: one being accumulated, one being activated
+    s16x8_t gf0[2] = {}, gf1[2] = {};  // two activated tiles (fc2's B operands): one being packed, one being consumed
+    if constexpr (TAIL) {     // (the last projection unit read no fragments ahead: over norm2 they would be spilled)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) wf[f] = ld_frag(base, f);
+    }
+    constexpr int WF = TAIL ? WAIT0 : -1;
+    load_bias(C_B1);
+    mlp_unit<DT, true, 0, WF>(st, base, wf, hf, xacc, ga, bias_c, gb, gf0, gf0);                     // fc1(0)
+    if (!TAIL) MLP_STAMP(1);
+    load_bias(C_B1 + 32);
+    mlp_unit<DT, true, 3, WF>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf0);                     // fc1(1) | gelu(0) -> gf0
+    load_bias(C_B1 + 64);
+    mlp_unit<DT, true, 1, WF>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1);                     // fc1(2) | gelu(1), values 0 .. 7
+    mlp_unit<DT, false, 2, WAIT0, !TAIL>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0);          // fc2(0) | gelu(1), values 8 .. 15
+    load_bias(C_B1 + 96);
     mlp_unit<DT, true, 1>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf0);                         // fc1(3) | gelu(2)
     mlp_unit<DT, false, 2>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf1);                        // fc2(1) | gelu(2)
     MLP_STAMP(2);
     for (int u = 2; u < UNITS - 2; u += 2) {
-      load_bias(u + 2);
+      load_bias(C_B1 + 32 * (u + 2));
       mlp_unit<DT, true, 1>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1);                       // fc1(u + 2) | gelu(u + 1)
       mlp_unit<DT, false, 2>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0);                      // fc2(u)     | gelu(u + 1)
-      load_bias(u + 3);
+      load_bias(C_B1 + 32 * (u + 3));
       mlp_unit<DT, true, 1>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf0);                       // fc1(u + 3) | gelu(u + 2)
       mlp_unit<DT, false, 2>(st, base, wf, hf, xacc, gb, bias_c, ga, gf0, gf1);                      // fc2(u + 1) | gelu(u + 2)
     }
     MLP_STAMP(3);
-    mlp_unit<DT, false, 3>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0);                          // fc2(46) | gelu(47) -> gf1
-    mlp_unit<DT, false, 0, 3 * PIECES, false, true>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1);   // fc2(47)
+    mlp_unit<DT, false, 3>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf0);                        // fc2(46) | gelu(47) -> gf1
+    mlp_unit<DT, false, 0, WAIT0, false, true>(st, base, wf, hf, xacc, ga, bias_c, gb, gf1, gf1);    // fc2(47)
 
-    // ---- epilogue: x[row][col .. col + 3] = acc + b2, lane owns row m, columns 32 ot + 8 g + 4 h + {0 .. 3}; then the
-    //      LayerNorm of the new row from the same registers (three passes, one output tile at a time: the compiler otherwise
-    //      keeps all 192 values in flight twice and spills the next tile's h) ----
+    // ---- epilogue: x[row][col .. col + 3] = [x +] acc + b2, lane owns row m, columns 32 ot + 8 g + 4 h + {0 .. 3}; then the
+    //      LayerNorm of the new row from the same registers (passes of one output tile at a time: the compiler otherwise
+    //      keeps all 192 values in flight twice and spills the next tile's fragments) ----
     MLP_STAMP(4);
-    // Everything this wave has requested has landed (the five images ahead: the first four units of the next tile wait for
-    // nothing but their barriers, so the stores below have until the fifth to drain -- vmcnt counts in order), and everybody
-    // has left the last image's slot: a quarter of it is this wave's staging space until the next unit refills it.
+    // Drain: everything this wave has requested has landed -- the four images ahead, so the first three units of the next
+    // tile wait for nothing but their barriers and the stores below have until the fourth to complete (vmcnt counts in
+    // order) -- and, behind the barrier, everybody's.
     // A lane owns a row: written as they stand, the accumulators would go out in 32-byte runs (two lanes per row), which a
-    // CU's store path takes at about 7 bytes per cycle.  So every output tile takes a turn through LDS: the residual rows
-    // come in eight lanes per row (128-byte runs, three tiles requested ahead), are read back a row per lane, and the sum
-    // goes the other way.  Row stride 144 bytes (36 banks).
+    // CU's memory path takes at about 7 bytes per cycle.  So every output tile takes a turn through this wave's staging
+    // rows: written a row per lane, read back eight lanes per row, stored in 128-byte runs; without the projection in front
+    // the residual columns come in the other way first (three tiles requested ahead).  Row stride 144 bytes (36 banks).
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    int ln = lane;             // (opaque: the addresses below are recomputed here, a few VALU per tile, not kept in -- spilled --
-    asm volatile("" : "+v"(ln));   //  registers across the units; the constants added to them stay immediate offsets)
-    const unsigned stg = (unsigned)(size_t)LDS_PTR(smem) + (st.slot == 0 ? NSLOT - 1 : st.slot - 1) * UB + wave * STG_BYTES;
-    const unsigned stg_wr = stg + (ln & 31) * STG_ROW + 16 * (ln >> 5);     // row per lane: + 32 g
-    const unsigned stg_wh = stg + (ln & 31) * STG_ROW + 8 * (ln >> 5);      // (16-bit rows: + 64 o2 + 16 g)
-    const unsigned stg_rd = stg + (ln >> 3) * STG_ROW + (ln & 7) * 16;      // eight lanes per row: + 8 i rows
-    const int xo = (wave * 32 + (ln >> 3)) * (D * 4) + (ln & 7) * 16;       // x: row 8 i + lane / 8, columns 32 ot + 4 (lane % 8) ..
-    const int ho = (wave * 32 + (ln >> 3)) * (D * 2) + (ln & 7) * 16;       // h: the same rows, columns 64 op + 8 (lane % 8) ..
-    // the next tile's h fragments: in flight during the whole epilogue
-    const int hfo = (wave * 32 + (ln & 31)) * (D * 2) + 16 * (ln >> 5);
+    int le = lane;             // (opaque again: everything the epilogue addresses is recomputed here, not carried over the units)
+    asm volatile("" : "+v"(le));
+    const unsigned stg_e = (unsigned)(size_t)LDS_PTR(smem) + STG_OFF + wave * STG_BYTES;
+    const unsigned stg_wr_e = stg_e + (le & 31) * STG_ROW + 16 * (le >> 5);
+    const unsigned stg_wh = stg_e + (le & 31) * STG_ROW + 8 * (le >> 5);      // (16-bit rows: + 64 o2 + 16 g)
+    const unsigned stg_rd_e = stg_e + (le >> 3) * STG_ROW + (le & 7) * 16;
+    const int xo_e = (wave * 32 + (le >> 3)) * (D * 4) + (le & 7) * 16;
+    const int ho = (wave * 32 + (le >> 3)) * (D * 2) + (le & 7) * 16;       // h: rows 8 i + lane / 8, columns 64 op + 8 (lane % 8) ..
+    // the next tile's activation fragments: in flight during the whole epilogue
+    const int hfo = (wave * 32 + (le & 31)) * (D * 2) + 16 * (le >> 5);
 #pragma unroll
     for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(io.h_next, hfo, 32 * s, 0));
-    constexpr int XA = 3;      // residual tiles requested ahead (deeper: no faster, measured)
-    u32x4_t xi[XA][4];
+    [[maybe_unused]] u32x4_t xi[XA][4];
     auto x_request = [&](int ot) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xi[ot % XA][i] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo + ot * 128, i * 8 * (D * 4), 0);
+      for (int i = 0; i < 4; ++i) xi[ot % XA][i] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo_e + ot * 128, i * 8 * (D * 4), 0);
     };
+    if constexpr (!TAIL) {
 #pragma unroll
-    for (int ot = 0; ot < XA; ++ot) x_request(ot);
+      for (int ot = 0; ot < XA; ++ot) x_request(ot);
+    }
     float s = 0.f;
 #pragma unroll
     for (int ot = 0; ot < D / 32; ++ot) {
+      if constexpr (!TAIL) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *(lds_w4_ptr)(stg_rd + i * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[ot % XA][i]);
-      if (ot + XA < D / 32) x_request(ot + XA);
+        for (int i = 0; i < 4; ++i) *(lds_w4_ptr)(stg_rd_e + i * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[ot % XA][i]);
+        if (ot + XA < D / 32) x_request(ot + XA);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 bv = cst4(HID + 32 * ot + 8 * g);
-        const f32x4_t xv = *(lds_f4_ptr)(stg_wr + 32 * g);
+        const float4 bv = cst4(C_B2 + 32 * ot + 8 * g);
         f32x4_t v;
-        v[0] = xv[0] + (xacc[ot][4 * g + 0] + bv.x); v[1] = xv[1] + (xacc[ot][4 * g + 1] + bv.y);
-        v[2] = xv[2] + (xacc[ot][4 * g + 2] + bv.z); v[3] = xv[3] + (xacc[ot][4 * g + 3] + bv.w);
+        v[0] = xacc[ot][4 * g + 0] + bv.x; v[1] = xacc[ot][4 * g + 1] + bv.y;
+        v[2] = xacc[ot][4 * g + 2] + bv.z; v[3] = xacc[ot][4 * g + 3] + bv.w;
+        if constexpr (!TAIL) {
+          const f32x4_t xv = *(lds_f4_ptr)(stg_wr_e + 32 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = xv[e] + v[e];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) xacc[ot][4 * g + e] = v[e];
-        *(lds_w4_ptr)(stg_wr + 32 * g) = v;
+        *(lds_w4_ptr)(stg_wr_e + 32 * g) = v;
         s += (v[0] + v[1]) + (v[2] + v[3]);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x4_t v = *(lds_f4_ptr)(stg_rd + i * 8 * STG_ROW);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.x, xo + ot * 128, i * 8 * (D * 4), 0);
+        const f32x4_t v = *(lds_f4_ptr)(stg_rd_e + i * 8 * STG_ROW);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.x, xo_e + ot * 128, i * 8 * (D * 4), 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -384,6 +544,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
       }
       MLP_STAMP(6);
       const float rstd = 1.0f / sqrtf(q / (float)D + ln_eps);
+      float mean_p = mean;
+      asm volatile("" : "+v"(mean_p));
 #pragma unroll
       for (int op = 0; op < D / 64; ++op) {            // two output tiles = 64 columns = 128 bytes of a 16-bit row
 #pragma unroll
@@ -392,17 +554,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int col = 32 * ot + 8 * g;
-            const float4 gg = cst4(HID + D + col);
-            const float4 bb = cst4(HID + 2 * D + col);
+            const float4 gg = cst4(C_G1 + col);
+            const float4 bb = cst4(C_E1 + col);
             u32x2_t pk;
-            pk[0] = pack2_h16<DT>((xacc[ot][4 * g + 0] - mean) * rstd * gg.x + bb.x, (xacc[ot][4 * g + 1] - mean) * rstd * gg.y + bb.y);
-            pk[1] = pack2_h16<DT>((xacc[ot][4 * g + 2] - mean) * rstd * gg.z + bb.z, (xacc[ot][4 * g + 3] - mean) * rstd * gg.w + bb.w);
+            pk[0] = pack2_h16<DT>((xacc[ot][4 * g + 0] - mean_p) * rstd * gg.x + bb.x, (xacc[ot][4 * g + 1] - mean_p) * rstd * gg.y + bb.y);
+            pk[1] = pack2_h16<DT>((xacc[ot][4 * g + 2] - mean_p) * rstd * gg.z + bb.z, (xacc[ot][4 * g + 3] - mean_p) * rstd * gg.w + bb.w);
             *(lds_w2_ptr)(stg_wh + 64 * o2 + 16 * g) = pk;
           }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const f32x4_t v = *(lds_f4_ptr)(stg_rd + i * 8 * STG_ROW);
+          const f32x4_t v = *(lds_f4_ptr)(stg_rd_e + i * 8 * STG_ROW);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.h_out, ho + op * 128, i * 8 * (D * 2), 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -421,12 +583,9 @@ extern "C" int vittf_mlp_stamps(unsigned long long* out) {      // [4][4][4][8][
 }
 #endif
 
-extern "C" int vittf_mlp_fused(const void* h, const void* w_packed, const float* b1, const float* b2, float* x, int64_t rows,
-                               int32_t d, int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out,
-                               void* stream) {
-  if (!h || !w_packed || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
-  if (d != D) return VITTF_ERR_INVALID_ARG;          // the register budget is sized for ViT-S
-  if ((ln_g || ln_b || h_out) && !(ln_g && ln_b && h_out)) return VITTF_ERR_INVALID_ARG;
+static int mlp_launch(bool tail, const void* a, const void* w_packed, const float* bp, const float* g2, const float* e2,
+                      const float* b1, const float* b2, float* x, int64_t rows, int32_t dtype, const float* ln_g,
+                      const float* ln_b, float ln_eps, void* h_out, void* stream) {
   const int64_t tiles = (rows + 127) / 128;
   if (tiles > 0x7fffffff) return VITTF_ERR_INVALID_ARG;
   static const int cus = [] {
@@ -436,13 +595,32 @@ extern "C" int vittf_mlp_fused(const void* h, const void* w_packed, const float*
   }();
   const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
   hipStream_t st = (hipStream_t)stream;
-#define MLP_LAUNCH(DTV)                                                                                              \
-  hipLaunchKernelGGL((mlp_kernel<DTV>), dim3(grid), dim3(256), 0, st, (const unsigned short*)h,                      \
-                     (const unsigned short*)w_packed, b1, b2, x, rows, ln_g, ln_b, ln_eps, (unsigned short*)h_out, (int)tiles)
-  if (dtype == VITTF_BF16) MLP_LAUNCH(VITTF_BF16);
-  else if (dtype == VITTF_FP16) MLP_LAUNCH(VITTF_FP16);
+#define MLP_LAUNCH(DTV, TAILV)                                                                                       \
+  hipLaunchKernelGGL((mlp_kernel<DTV, TAILV>), dim3(grid), dim3(256), 0, st, (const unsigned short*)a,               \
+                     (const unsigned short*)w_packed, bp, g2, e2, b1, b2, x, rows, ln_g, ln_b, ln_eps,               \
+                     (unsigned short*)h_out, (int)tiles)
+  if (dtype == VITTF_BF16) { if (tail) MLP_LAUNCH(VITTF_BF16, true); else MLP_LAUNCH(VITTF_BF16, false); }
+  else if (dtype == VITTF_FP16) { if (tail) MLP_LAUNCH(VITTF_FP16, true); else MLP_LAUNCH(VITTF_FP16, false); }
   else return VITTF_ERR_INVALID_ARG;
 #undef MLP_LAUNCH
-  vittf_note_kernel(VITTF_KERNEL_MLP, "mlp_kernel");
+  vittf_note_kernel(VITTF_KERNEL_MLP, tail ? "mlp_kernel<block tail>" : "mlp_kernel");
   return vittf_check_launch();
+}
+
+extern "C" int vittf_mlp_fused(const void* h, const void* w_packed, const float* b1, const float* b2, float* x, int64_t rows,
+                               int32_t d, int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out,
+                               void* stream) {
+  if (!h || !w_packed || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
+  if (d != D) return VITTF_ERR_INVALID_ARG;          // the register budget is sized for ViT-S
+  if ((ln_g || ln_b || h_out) && !(ln_g && ln_b && h_out)) return VITTF_ERR_INVALID_ARG;
+  return mlp_launch(false, h, w_packed, nullptr, nullptr, nullptr, b1, b2, x, rows, dtype, ln_g, ln_b, ln_eps, h_out, stream);
+}
+
+extern "C" int vittf_block_tail(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g,
+                                const float* ln2_b, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
+                                int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* stream) {
+  if (!attn_out || !w_packed || !proj_b || !ln2_g || !ln2_b || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
+  if (d != D) return VITTF_ERR_INVALID_ARG;
+  if ((ln_g || ln_b || h_out) && !(ln_g && ln_b && h_out)) return VITTF_ERR_INVALID_ARG;
+  return mlp_launch(true, attn_out, w_packed, proj_b, ln2_g, ln2_b, b1, b2, x, rows, dtype, ln_g, ln_b, ln_eps, h_out, stream);
 }

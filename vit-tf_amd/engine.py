@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .weights import arch_of, fold_patch_embed, interpolate_pos_embed, pack_mlp_weights
+from .weights import arch_of, fold_patch_embed, interpolate_pos_embed, pack_block_tail_weights, pack_mlp_weights
 
 _TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.FP16: torch.float16}
 
@@ -35,7 +35,7 @@ class HipViT:
     attention path (e4m3 operands on the block-scaled matrix instruction; ~3e-2 on the features: opt-in).
     """
 
-    def __init__(self, state_dict, arch='vits8', dtype='fp16', device=None, fused_mlp=None, attention='16bit'):
+    def __init__(self, state_dict, arch='vits8', dtype='fp16', device=None, fused_mlp=None, attention='16bit', fused_tail=None):
         self.lib = _lib.require_device()
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         dim, depth, heads, patch = arch_of(arch)
@@ -68,11 +68,17 @@ class HipViT:
             'ln2_g': stack('blocks.{}.norm2.weight', torch.float32), 'ln2_b': stack('blocks.{}.norm2.bias', torch.float32),
         }
         ptrs = {k: v.data_ptr() for k, v in self._t.items()}
-        ptrs['mlp_packed'] = None
-        if fused_mlp is None:                   # D = 384: the fused fc1 -> GELU -> fc2 (+ LayerNorm) kernel (csrc/mlp.hip)
-            import os
+        ptrs['mlp_packed'] = ptrs['tail_packed'] = None
+        import os
+        if fused_tail is None:                  # D = 384: everything behind the attention of a block in one launch (csrc/mlp.hip)
+            fused_tail = (os.environ.get('VITTF_FUSED_TAIL', '1') == '1' and os.environ.get('VITTF_FUSED_MLP', '1') == '1'
+                          and fused_mlp is not False)
+        if fused_mlp is None:                   # ... or at least fc1 -> GELU -> fc2 (+ LayerNorm) of it
             fused_mlp = os.environ.get('VITTF_FUSED_MLP', '1') == '1'
-        if fused_mlp and dim == 384:           # the fused MLP kernel's register budget is sized for ViT-S
+        if fused_tail and dim == 384:          # the kernel's register budget is sized for ViT-S
+            self._t['tail_packed'] = pack_block_tail_weights(self._t['proj_w'], self._t['fc1_w'], self._t['fc2_w'])
+            ptrs['tail_packed'] = self._t['tail_packed'].data_ptr()
+        elif fused_mlp and dim == 384:
             self._t['mlp_packed'] = pack_mlp_weights(self._t['fc1_w'], self._t['fc2_w'])
             ptrs['mlp_packed'] = self._t['mlp_packed'].data_ptr()
         self.weights = _lib.VitWeights(**ptrs)

@@ -195,6 +195,38 @@ def _tile_pos_tables():
     return (p << 1) | (slot >> 3), slot & 7
 
 
+def _pack_row_images(w):
+    """[L, 32 U, 384] -> [L, U, 12288]: image u = rows 32 u .. + 31 over the 384 inputs as 6 sub-images [32 rows][64 k] in LDS
+    layout: element (s6, q, e) = w[32 u + r[q], 64 s6 + 8 c[q] + e]."""
+    L, n, d = w.shape
+    assert d == 384 and n % 32 == 0
+    units, dev = n // 32, w.device
+    r, c = (t.to(dev) for t in _tile_pos_tables())
+    e = torch.arange(8, device=dev)
+    s6 = torch.arange(6, device=dev)
+    rows = torch.arange(units, device=dev).view(-1, 1, 1, 1) * 32 + r.view(1, 1, -1, 1)                # [U, 1, 256, 1]
+    cols = (64 * s6.view(1, -1, 1, 1) + 8 * c.view(1, 1, -1, 1) + e.view(1, 1, 1, -1))                  # [1, 6, 256, 8]
+    return w[:, rows.expand(units, 6, 256, 8), cols.expand(units, 6, 256, 8)].reshape(L, units, -1)
+
+
+def norm2_register_order():
+    """Column of x held at fc1 input position 16 s + 8 h + e when norm2 is computed in the block-tail kernel's accumulator
+    registers (csrc/mlp.hip): 32 (s >> 1) + 16 (s & 1) + 8 (e >> 2) + 4 h + (e & 3)."""
+    p = torch.arange(384)
+    s_, h, e = p >> 4, (p >> 3) & 1, p & 7
+    return 32 * (s_ >> 1) + 16 * (s_ & 1) + 8 * (e >> 2) + 4 * h + (e & 3)
+
+
+def pack_block_tail_weights(wp, w1, w2):
+    """proj / fc1 / fc2 weights of L blocks -> the stream of the block-tail kernel (vittf_block_tail): per block 12 images
+    of the projection (Wp rows 32 ot .. + 31 over the 384 attention outputs), then the MLP's 96 with fc1's input dim in the
+    order norm2 leaves its values in the registers.  wp: [L, D, D], w1: [L, 4D, D], w2: [L, D, 4D] -> [L, 108, 12288]."""
+    L, d, d2 = wp.shape
+    assert d == 384 and d2 == 384
+    order = norm2_register_order().to(w1.device)
+    return torch.cat([_pack_row_images(wp), pack_mlp_weights(w1[:, :, order], w2)], dim=1).contiguous()
+
+
 def pack_mlp_weights(w1, w2):
     """fc1 / fc2 weights of L blocks -> the stream the fused MLP kernel (csrc/mlp.hip) consumes: per block 96 images of
     24 KB in consumption order W1(0), W1(1), W1(2), W2(0), W1(3), W2(1), .., W1(47), W2(45), W2(46), W2(47), each image = 6 sub-images of
@@ -210,10 +242,7 @@ def pack_mlp_weights(w1, w2):
     r, c = (t.to(dev) for t in _tile_pos_tables())                      # [256]
     e = torch.arange(8, device=dev)
     s6 = torch.arange(6, device=dev)
-    # W1(u): element (s6, q, e) = w1[32 u + r[q], 64 s6 + 8 c[q] + e]
-    rows1 = torch.arange(units, device=dev).view(-1, 1, 1, 1) * 32 + r.view(1, 1, -1, 1)               # [U, 1, 256, 1]
-    cols1 = (64 * s6.view(1, -1, 1, 1) + 8 * c.view(1, 1, -1, 1) + e.view(1, 1, 1, -1))                 # [1, 6, 256, 8]
-    img1 = w1[:, rows1.expand(units, 6, 256, 8), cols1.expand(units, 6, 256, 8)].reshape(L, units, -1)
+    img1 = _pack_row_images(w1)
     # W2(u): element (s6, q, e) = w2p[32 (2 s6 + (c >> 2)) + r, 32 u + 16 ((c >> 1) & 1) + 8 (c & 1) + e]
     w2p = permute_fc2_hidden(w2)
     rows2 = (32 * (2 * s6.view(1, -1, 1, 1) + (c.view(1, 1, -1, 1) >> 2)) + r.view(1, 1, -1, 1))       # [1, 6, 256, 1]
