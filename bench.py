@@ -356,13 +356,15 @@ def main():
 
     flop_slice = vit_flops(n_tokens, dim, depth, patch)
     slices_done = my_slices * args.steps
-    if prof['mlp'][1] > 0:          # fused MLP: fc1 + fc2 in one kernel
+    if prof['mlp'][1] > 0:          # fused MLP: fc1 + fc2 in one kernel ...
         flop_slice['mlp'] = flop_slice.pop('gemm_fc1') + flop_slice.pop('gemm_fc2')
+        if prof['gemm_proj'][1] == 0:   # ... block tail: with the attention projection in front of them
+            flop_slice['mlp'] += flop_slice.pop('gemm_proj')
     flops = {k: v * slices_done for k, v in flop_slice.items()}
     kernels = {'attention': f"{vt._lib.kernel_name('attention')}<{args.dtype}>", 'gemm_qkv': f'gemm_ws_kernel<{args.dtype}, qkv>',
                'gemm_fc1': f'gemm_ws_kernel<{args.dtype}, fc1+gelu>', 'gemm_proj': f'gemm_rows_kernel<{args.dtype}, proj+ln>',
                'gemm_fc2': f'gemm_rows_kernel<{args.dtype}, fc2+ln>', 'gemm': f'gemm_kernel<{args.dtype}, kfeat>',
-               'mlp': f'mlp_kernel<{args.dtype}>', 'patch_embed': 'patch_embed_kernel', 'layernorm': 'layernorm_kernel'}
+               'mlp': f"{vt._lib.kernel_name('mlp') or 'mlp_kernel'}<{args.dtype}>", 'patch_embed': 'patch_embed_kernel', 'layernorm': 'layernorm_kernel'}
     # the kernel with the largest share of the step
     dom = max((k for k in prof if k in flops), key=lambda k: prof[k][0])
     dom_ms, dom_launches = prof[dom]

@@ -234,7 +234,7 @@ def test_fused_mlp_kernel_register_contract():
     r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'kernel_asm.sh'), 'mlp.hip'], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     usage = [l for l in r.stdout.splitlines() if 'mlp_kernel' in l and 'ScratchSize' in l]
-    assert len(usage) == 2, r.stdout                                       # bf16 and fp16
+    assert len(usage) == 4, r.stdout                                       # bf16 and fp16, with and without the projection in front
     for l in usage:
         assert 'ScratchSize [bytes/lane]: 0 ' in l and 'VGPRs Spill: 0' in l and 'Occupancy [waves/SIMD]: 1' in l, l
     asm = open('/tmp/vittf_asm/mlp.s').read()

@@ -14,7 +14,9 @@ def main():
     g = torch.Generator().manual_seed(0)
     w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).half().to(dev)
     w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).half().to(dev)
-    wpk = vt.weights.pack_mlp_weights(w1[None], w2[None])[0].contiguous()
+    tail = os.environ.get('TAIL', '0') == '1'          # the block-tail kernel (projection + norm2 in front of the MLP)
+    wp = (torch.randn(d, d, generator=g) / d ** 0.5).half().to(dev)
+    wpk = (vt.weights.pack_block_tail_weights(wp[None], w1[None], w2[None]) if tail else vt.weights.pack_mlp_weights(w1[None], w2[None]))[0].contiguous()
     b1 = torch.randn(4 * d, generator=g).to(dev); b2 = torch.randn(d, generator=g).to(dev)
     hh = torch.randn(rows, d, generator=g).half().to(dev)
     lg = torch.ones(d, device=dev); lb = torch.zeros(d, device=dev)
@@ -25,20 +27,21 @@ def main():
     fns = []
     for p in libs:
         lib = ctypes.CDLL(p)
-        f = lib.vittf_mlp_fused
+        f = lib.vittf_block_tail if tail else lib.vittf_mlp_fused
         f.restype = ctypes.c_int
-        f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
-                                              ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+        f.argtypes = ([ctypes.c_void_p] * (8 if tail else 5) + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                                                ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p])
         fns.append((re.search(r'_v(\w+)\.so', p).group(1), f))
 
     def run(f):
-        rc = f(hh.data_ptr(), wpk.data_ptr(), b1.data_ptr(), b2.data_ptr(), x.data_ptr(), rows, d, _lib.DTYPES['fp16'],
+        pre = (hh.data_ptr(), wpk.data_ptr(), b2.data_ptr(), lg.data_ptr(), lb.data_ptr()) if tail else (hh.data_ptr(), wpk.data_ptr())
+        rc = f(*pre, b1.data_ptr(), b2.data_ptr(), x.data_ptr(), rows, d, _lib.DTYPES['fp16'],
                lg.data_ptr(), lb.data_ptr(), 1e-6, hn.data_ptr(), _lib.stream_ptr())
         assert rc == 0, rc
     for _, f in fns:
         run(f)
     torch.cuda.synchronize()
-    fl = 16 * rows * d * d
+    fl = (18 if tail else 16) * rows * d * d
     for rnd in range(3):               # interleaved rounds: clock drift shows as a spread between rounds, not between variants
         for v, f in fns:
             x.zero_()
@@ -64,7 +67,7 @@ def stamps(libs, v='16'):
     lib = ctypes.CDLL(p)
     buf = np.zeros((4, 4, 4, 8, 2), np.uint64)
     assert lib.vittf_mlp_stamps(ctypes.c_void_p(buf.ctypes.data)) == 0
-    names = ['top -> unit 0 done', 'units 1 .. 5', 'units 6 .. 93', 'units 94, 95', 'h loads issued + x = acc + b2, stores', 'LayerNorm statistics',
+    names = ['top -> unit 0 done (TAIL=1: projection units)', 'units 1 .. 5 (TAIL=1: norm2 + units 0 .. 5)', 'units 6 .. 93', 'units 94, 95', 'h loads issued + x = acc + b2, stores', 'LayerNorm statistics',
              'normalise + h stores', 'to the next tile top']
     cyc = buf[..., 0].astype(np.int64)
     for wg in range(2):

@@ -13,7 +13,7 @@ rm -f "$tools"/micro/build/libmlp_v*.so
 for spec in "$@"; do        # "bits" or "bits:tag:extra flag" (e.g. 0:1:-DMLP_HP=1 -> libmlp_v0_1.so)
   v=${spec%%:*}; rest=${spec#*:}; tag=""; extra=""
   if [ "$rest" != "$spec" ]; then tag="_${rest%%:*}"; extra=${rest#*:}; fi
-  /opt/rocm/bin/hipcc $flags -DMLP_VARIANT=$v $extra -shared mlp.hip -o "$tools/micro/build/libmlp_v$v$tag.so" &
+  /opt/rocm/bin/hipcc $flags -DMLP_VARIANT=$v -DMLP_STANDALONE $extra -shared mlp.hip -o "$tools/micro/build/libmlp_v$v$tag.so" &
 done
 wait
 ls -la "$tools/micro/build"
