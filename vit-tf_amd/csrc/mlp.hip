@@ -35,6 +35,9 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 namespace {
 
 constexpr int D = 384, HID = 4 * D;
@@ -52,7 +55,8 @@ constexpr int CONST_OFF = STG_OFF + UB;    // fp32 constants behind that, in flo
 constexpr int C_B1 = 0, C_B2 = HID, C_G1 = HID + D, C_E1 = HID + 2 * D,       // b1 | b2 | gamma, beta of the LayerNorm behind the MLP
               C_BP = HID + 3 * D, C_G2 = HID + 4 * D, C_E2 = HID + 5 * D,      // block tail: proj bias | gamma, beta of norm2
               C_N = HID + 6 * D;
-constexpr int LDS_BYTES = CONST_OFF + C_N * 4;
+constexpr int NEXT_OFF = CONST_OFF + C_N * 4;     // one word: the tile the workgroup takes next
+constexpr int LDS_BYTES = NEXT_OFF + 16;
 constexpr int XA = 3;                      // residual tiles (32 columns) requested ahead (deeper: no faster, measured)
 static_assert(32 * STG_ROW <= STG_BYTES, "staging");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
                                                      const float* __restrict__ b1, const float* __restrict__ b2,
                                                      float* __restrict__ x, int64_t rows, const float* __restrict__ ln_g,
                                                      const float* __restrict__ ln_b, float ln_eps,
-                                                     unsigned short* __restrict__ hout, int ntiles) {
+                                                     unsigned short* __restrict__ hout, int ntiles,
+                                                     unsigned* __restrict__ tile_ctr) {
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -290,6 +295,15 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
   unsigned cl = (unsigned)(size_t)LDS_PTR(smem) + CONST_OFF + 16 * h;
   asm volatile("" : "+v"(cl));
   auto cst4 = [&](int i) { const f32x4_t v = *(lds_f4_ptr)(cl + 4 * i); return make_float4(v[0], v[1], v[2], v[3]); };      // floats i .. i + 3 (+ 4 h) of the constants
+  // Tiles are handed out by a counter (the next one is asked for at the top of a tile and picked up in its epilogue): the
+  // launch then ends when the tiles do, not when the workgroup with one tile more than the others does -- 8194 tiles on
+  // 256 CUs are 32.01 rounds, not 33.  (Start offsets between the workgroups on top of it, so that they do not all reach
+  // their epilogues together: measured, no effect on the launch time at 0, 1/16, 1/8 and 3/16 of a tile per phase.)
+  volatile unsigned* const nxt = reinterpret_cast<volatile unsigned*>(smem + NEXT_OFF);
+  if (tid == 0) *nxt = atomicAdd(tile_ctr, 1u);
+  __syncthreads();
+  int tile = __builtin_amdgcn_readfirstlane((int)*nxt);
+  if (tile >= ntiles) return;                  // (nothing requested yet)
   Stream st;
   st.nseq = TAIL ? PUNITS + 2 * UNITS : 2 * UNITS;
   st.rsrc = lds_dma_rsrc(wpk, (unsigned)(st.nseq * UB));
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
   // ---- this lane's activation fragments (B operand) of the first tile: A[row][16 s + 8 h .. + 7], s = 0 .. 23 ----
   s16x8_t hf[D / 16];
   {
-    const auto rs = tile_rsrc(abuf, blockIdx.x, D * 2);
+    const auto rs = tile_rsrc(abuf, tile, D * 2);
 #pragma unroll
     for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (wave * 32 + l31) * (D * 2) + 16 * h, 32 * s, 0));
   }
@@ -327,16 +341,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
 
   [[maybe_unused]] int tile_no = -1;
   [[maybe_unused]] unsigned long long stamp_[8];
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  while (true) {
     ++tile_no;
     MLP_STAMP(0);
+    unsigned next_v = 0;       // the tile after this one: asked for now, picked up in the epilogue
+    if (tid == 0) next_v = atomicAdd(tile_ctr, 1u);
     // the first fragments of the tile's first image (landed: the drain in front of the previous epilogue / above).  Every
     // other unit reads its first eight fragments behind the last MFMAs of the unit before it; carried over the epilogue
     // they would be spilled
 #pragma unroll
     for (int f = 0; f < NF; ++f) wf[f] = ld_frag(base, f);
     io.x = tile_rsrc(x, tile, D * 4);
-    io.h_next = tile_rsrc(abuf, (int64_t)tile + gridDim.x, D * 2);      // (no next tile: an empty descriptor)
     io.h_out = tile_rsrc(hout, tile, D * 2);
     int ln = lane;             // (opaque: the addresses below are recomputed per tile, a few VALU, not kept in -- spilled --
     asm volatile("" : "+v"(ln));   //  registers across the units; the constants added to them stay immediate offsets)
@@ -479,7 +494,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
     // CU's memory path takes at about 7 bytes per cycle.  So every output tile takes a turn through this wave's staging
     // rows: written a row per lane, read back eight lanes per row, stored in 128-byte runs; without the projection in front
     // the residual columns come in the other way first (three tiles requested ahead).  Row stride 144 bytes (36 banks).
+    if (tid == 0) *nxt = next_v;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int next = __builtin_amdgcn_readfirstlane((int)*nxt);
+    io.h_next = tile_rsrc(abuf, next, D * 2);      // (no next tile: an empty descriptor)
     int le = lane;             // (opaque again: everything the epilogue addresses is recomputed here, not carried over the units)
     asm volatile("" : "+v"(le));
     const unsigned stg_e = (unsigned)(size_t)LDS_PTR(smem) + STG_OFF + wave * STG_BYTES;
@@ -490,24 +508,28 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
     const int ho = (wave * 32 + (le >> 3)) * (D * 2) + (le & 7) * 16;       // h: rows 8 i + lane / 8, columns 64 op + 8 (lane % 8) ..
     // the next tile's activation fragments: in flight during the whole epilogue
     const int hfo = (wave * 32 + (le & 31)) * (D * 2) + 16 * (le >> 5);
+    auto request_next_fragments = [&] {
 #pragma unroll
-    for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(io.h_next, hfo, 32 * s, 0));
-    [[maybe_unused]] u32x4_t xi[XA][4];
+      for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(io.h_next, hfo, 32 * s, 0));
+    };
+    if constexpr (TAIL) request_next_fragments();      // (the MLP alone: behind the residual pass, whose chunk registers they would spill)
+    constexpr int XE = 3;      // (the MLP alone: residual tiles requested ahead in the epilogue)
+    [[maybe_unused]] u32x4_t xi[XE][4];
     auto x_request = [&](int ot) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xi[ot % XA][i] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo_e + ot * 128, i * 8 * (D * 4), 0);
+      for (int i = 0; i < 4; ++i) xi[ot % XE][i] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo_e + ot * 128, i * 8 * (D * 4), 0);
     };
     if constexpr (!TAIL) {
 #pragma unroll
-      for (int ot = 0; ot < XA; ++ot) x_request(ot);
+      for (int ot = 0; ot < XE; ++ot) x_request(ot);
     }
     float s = 0.f;
 #pragma unroll
     for (int ot = 0; ot < D / 32; ++ot) {
       if constexpr (!TAIL) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(lds_w4_ptr)(stg_rd_e + i * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[ot % XA][i]);
-        if (ot + XA < D / 32) x_request(ot + XA);
+        for (int i = 0; i < 4; ++i) *(lds_w4_ptr)(stg_rd_e + i * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[ot % XE][i]);
+        if (ot + XE < D / 32) x_request(ot + XE);
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -533,6 +555,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
       __builtin_amdgcn_sched_barrier(0);
     }
     MLP_STAMP(5);
+    if constexpr (!TAIL) request_next_fragments();
     if (hout) {
       {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
@@ -579,6 +602,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
       }
     }
     MLP_STAMP(7);
+    if (next >= ntiles) break;
+    tile = next;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the images requested beyond the last unit: land before the LDS goes away
 }
@@ -607,10 +632,25 @@ static int mlp_launch(bool tail, const void* a, const void* w_packed, const floa
   }();
   const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
   hipStream_t st = (hipStream_t)stream;
+  // the tile counter of this stream (launches on one stream are serialised; two stream lanes run two of these kernels at once)
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, unsigned*> counters;
+  unsigned* ctr = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = counters.find(st);
+    if (it == counters.end()) {
+      if (hipMalloc((void**)&ctr, sizeof(unsigned)) != hipSuccess) return VITTF_ERR_LAUNCH;
+      counters.emplace(st, ctr);
+    } else {
+      ctr = it->second;
+    }
+  }
+  if (hipMemsetAsync(ctr, 0, sizeof(unsigned), st) != hipSuccess) return VITTF_ERR_LAUNCH;
 #define MLP_LAUNCH(DTV, TAILV)                                                                                       \
   hipLaunchKernelGGL((mlp_kernel<DTV, TAILV>), dim3(grid), dim3(256), 0, st, (const unsigned short*)a,               \
                      (const unsigned short*)w_packed, bp, g2, e2, b1, b2, x, rows, ln_g, ln_b, ln_eps,               \
-                     (unsigned short*)h_out, (int)tiles)
+                     (unsigned short*)h_out, (int)tiles, ctr)
   if (dtype == VITTF_BF16) { if (tail) MLP_LAUNCH(VITTF_BF16, true); else MLP_LAUNCH(VITTF_BF16, false); }
   else if (dtype == VITTF_FP16) { if (tail) MLP_LAUNCH(VITTF_FP16, true); else MLP_LAUNCH(VITTF_FP16, false); }
   else return VITTF_ERR_INVALID_ARG;
