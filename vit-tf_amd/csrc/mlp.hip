@@ -338,6 +338,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first AHEAD images have landed (only here: the unit waits count
   __syncthreads();                                       // on a steady stream) ... everybody's pieces; the constants are written
   s16x8_t wf[NF];
+  // block tail: the first residual chunks of a tile are requested before the stores of the tile in front of it (vmcnt retires
+  // in order: behind them they would arrive when the last store has, a fifth of a tile later)
+  [[maybe_unused]] u32x4_t xin[XA][4];
+  if constexpr (TAIL) {
+    const auto rx = tile_rsrc(x, tile, D * 4);
+    const int xo0 = (wave * 32 + (lane >> 3)) * (D * 4) + (lane & 7) * 16;
+#pragma unroll
+    for (int c = 0; c < XA; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xin[c][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo0 + c * 128, i * 8 * (D * 4), 0);
+  }
 
   [[maybe_unused]] int tile_no = -1;
   [[maybe_unused]] unsigned long long stamp_[8];
@@ -373,13 +384,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
       // ---- x' = x + proj(a) + bp, one output tile per unit; the residual chunks come in beside the units (three in flight).
       //      The first three units wait for nothing but their barriers (their images landed before the drain); from then on
       //      the counted wait also counts the four chunk loads per unit of the two units before. ----
-      u32x4_t xi[XA][4];
-#pragma unroll
-      for (int c = 0; c < XA; ++c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xi[c][i] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo + c * 128, i * 8 * (D * 4), 0);
 #define PROJ_UNIT(OT, WAITN) load_bias(C_BP + 32 * (OT)); \
-      proj_unit<DT, OT, WAITN, ((OT) >= 1 && (OT) - 1 + XA < PUNITS), (OT) == PUNITS - 1>(st, base, wf, hf, xacc, bias_c, xi, io, xo, stg_rd, stg_wr)
+      proj_unit<DT, OT, WAITN, ((OT) >= 1 && (OT) - 1 + XA < PUNITS), (OT) == PUNITS - 1>(st, base, wf, hf, xacc, bias_c, xin, io, xo, stg_rd, stg_wr)
       PROJ_UNIT(0, -1); PROJ_UNIT(1, -1); PROJ_UNIT(2, -1);
       PROJ_UNIT(3, WAIT0 + 8); PROJ_UNIT(4, WAIT0 + 8); PROJ_UNIT(5, WAIT0 + 8); PROJ_UNIT(6, WAIT0 + 8);
       PROJ_UNIT(7, WAIT0 + 8); PROJ_UNIT(8, WAIT0 + 8); PROJ_UNIT(9, WAIT0 + 8); PROJ_UNIT(10, WAIT0 + 8);
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
       MLP_STAMP(1);
       {                       // the last tile's chunk
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(lds_w4_ptr)(stg_rd + i * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[(PUNITS - 1) % XA][i]);
+        for (int i = 0; i < 4; ++i) *(lds_w4_ptr)(stg_rd + i * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xin[(PUNITS - 1) % XA][i]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4_t xv = *(lds_f4_ptr)(stg_wr + 32 * g);
@@ -512,7 +518,14 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
 #pragma unroll
       for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(io.h_next, hfo, 32 * s, 0));
     };
-    if constexpr (TAIL) request_next_fragments();      // (the MLP alone: behind the residual pass, whose chunk registers they would spill)
+    if constexpr (TAIL) {       // (the MLP alone: behind the residual pass, whose chunk registers they would spill)
+      request_next_fragments();
+      const auto rx = tile_rsrc(x, next, D * 4);
+#pragma unroll
+      for (int c = 0; c < XA; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xin[c][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo_e + c * 128, i * 8 * (D * 4), 0);
+    }
     constexpr int XE = 3;      // (the MLP alone: residual tiles requested ahead in the epilogue)
     [[maybe_unused]] u32x4_t xi[XE][4];
     auto x_request = [&](int ot) {
