@@ -10,6 +10,7 @@ last_json() { grep -E '^\{"metric"' "$1" | tail -1; }
 f=$(ls -t $O/prof512/runc/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $P/${tag}_bench512_kernel_stats.csv
 [ -f $O/pmc_attn256.log ] && cp $O/pmc_attn256.log $P/${tag}_attention_pmc.txt
 [ -f $O/pmc_sim.log ] && cp $O/pmc_sim.log $P/${tag}_similarity_pmc.txt
+[ -f $O/pmc_tail.log ] && cp $O/pmc_tail.log $P/${tag}_block_tail_pmc.txt
 [ -f $O/pmc_attention.json ] && cp $O/pmc_attention.json $P/pmc_attention.json
 [ -f $O/pmc_similarity.json ] && cp $O/pmc_similarity.json $P/pmc_similarity.json
 for t in kernels pipeline fullsize; do [ -f $O/test_$t.log ] && tail -n 40 $O/test_$t.log > $P/${tag}_test_$t.tail.txt; done
