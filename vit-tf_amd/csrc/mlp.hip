@@ -84,6 +84,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((address_space(3))) const f32x4_t* lds_f4_ptr;
 typedef __attribute__((address_space(3))) f32x4_t* lds_w4_ptr;
 typedef __attribute__((address_space(3))) u32x2_t* lds_w2_ptr;
+typedef __attribute__((address_space(3))) volatile unsigned* lds_u32_ptr;
 __device__ __forceinline__ s16x8_t ld_frag(const unsigned (&base)[4], int f) {
   return *(lds_frag_ptr)(base[f & 3] + (f >> 2) * 4096);
 }
@@ -299,10 +300,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
   // launch then ends when the tiles do, not when the workgroup with one tile more than the others does -- 8194 tiles on
   // 256 CUs are 32.01 rounds, not 33.  (Start offsets between the workgroups on top of it, so that they do not all reach
   // their epilogues together: measured, no effect on the launch time at 0, 1/16, 1/8 and 3/16 of a tile per phase.)
-  volatile unsigned* const nxt = reinterpret_cast<volatile unsigned*>(smem + NEXT_OFF);
-  if (tid == 0) *nxt = atomicAdd(tile_ctr, 1u);
+  const unsigned nxt = (unsigned)(size_t)LDS_PTR(smem) + NEXT_OFF;      // (an LDS address, not a generic pointer: no flat loads)
+  if (tid == 0) *(lds_u32_ptr)nxt = atomicAdd(tile_ctr, 1u);
   __syncthreads();
-  int tile = __builtin_amdgcn_readfirstlane((int)*nxt);
+  int tile = __builtin_amdgcn_readfirstlane((int)*(lds_u32_ptr)nxt);
   if (tile >= ntiles) return;                  // (nothing requested yet)
   Stream st;
   st.nseq = TAIL ? PUNITS + 2 * UNITS : 2 * UNITS;
@@ -500,9 +501,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
     // CU's memory path takes at about 7 bytes per cycle.  So every output tile takes a turn through this wave's staging
     // rows: written a row per lane, read back eight lanes per row, stored in 128-byte runs; without the projection in front
     // the residual columns come in the other way first (three tiles requested ahead).  Row stride 144 bytes (36 banks).
-    if (tid == 0) *nxt = next_v;
+    if (tid == 0) *(lds_u32_ptr)nxt = next_v;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const int next = __builtin_amdgcn_readfirstlane((int)*nxt);
+    const int next = __builtin_amdgcn_readfirstlane((int)*(lds_u32_ptr)nxt);
     io.h_next = tile_rsrc(abuf, next, D * 2);      // (no next tile: an empty descriptor)
     int le = lane;             // (opaque again: everything the epilogue addresses is recomputed here, not carried over the units)
     asm volatile("" : "+v"(le));
