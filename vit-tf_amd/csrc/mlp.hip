@@ -57,7 +57,7 @@ constexpr int C_B1 = 0, C_B2 = HID, C_G1 = HID + D, C_E1 = HID + 2 * D,       //
               C_N = HID + 6 * D;
 constexpr int NEXT_OFF = CONST_OFF + C_N * 4;     // one word: the tile the workgroup takes next
 constexpr int LDS_BYTES = NEXT_OFF + 16;
-constexpr int XA = 3;                      // residual tiles (32 columns) requested ahead (deeper: no faster, measured)
+constexpr int XA = 3;                      // residual tiles (32 columns) requested ahead (6: no faster, measured twice)
 static_assert(32 * STG_ROW <= STG_BYTES, "staging");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 
@@ -166,6 +166,12 @@ __device__ __forceinline__ void stream_gap(const Stream& st, unsigned (&base)[4]
     else lds_dma16_keep(st.rsrc, dst, (int)((threadIdx.x & 63) * 16), src);
   }
 }
+
+// chunk loads projection unit t issues (it folds chunk t - 1 in and asks for chunk t - 1 + XA), and the counted wait in front
+// of unit t: the first three run behind a drain, the others count the loads of the two units before them
+constexpr int proj_requests(int t) { return t >= 1 && t - 1 + XA < PUNITS ? 4 : 0; }
+constexpr int proj_wait(int t) { return t < 3 ? -1 : WAIT0 + proj_requests(t - 2) + proj_requests(t - 1); }
+static_assert(proj_requests(PUNITS - 2) == 0 && proj_requests(PUNITS - 1) == 0, "the MLP's first units count pieces only");
 
 // One projection unit of the block tail = 24 MFMAs: xacc[OT] = Wp rows 32 OT .. + 31 . a^T (+ the bias tile as initial value).
 // In its gaps the residual columns of the tile BEFORE it (whose product is complete) are folded in: the chunk requested
@@ -385,12 +391,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
       // ---- x' = x + proj(a) + bp, one output tile per unit; the residual chunks come in beside the units (three in flight).
       //      The first three units wait for nothing but their barriers (their images landed before the drain); from then on
       //      the counted wait also counts the four chunk loads per unit of the two units before. ----
-#define PROJ_UNIT(OT, WAITN) load_bias(C_BP + 32 * (OT)); \
-      proj_unit<DT, OT, WAITN, ((OT) >= 1 && (OT) - 1 + XA < PUNITS), (OT) == PUNITS - 1>(st, base, wf, hf, xacc, bias_c, xin, io, xo, stg_rd, stg_wr)
-      PROJ_UNIT(0, -1); PROJ_UNIT(1, -1); PROJ_UNIT(2, -1);
-      PROJ_UNIT(3, WAIT0 + 8); PROJ_UNIT(4, WAIT0 + 8); PROJ_UNIT(5, WAIT0 + 8); PROJ_UNIT(6, WAIT0 + 8);
-      PROJ_UNIT(7, WAIT0 + 8); PROJ_UNIT(8, WAIT0 + 8); PROJ_UNIT(9, WAIT0 + 8); PROJ_UNIT(10, WAIT0 + 8);
-      PROJ_UNIT(11, WAIT0 + 4);
+#define PROJ_UNIT(OT) load_bias(C_BP + 32 * (OT)); \
+      proj_unit<DT, OT, proj_wait(OT), proj_requests(OT) != 0, (OT) == PUNITS - 1>(st, base, wf, hf, xacc, bias_c, xin, io, xo, stg_rd, stg_wr)
+      PROJ_UNIT(0); PROJ_UNIT(1); PROJ_UNIT(2); PROJ_UNIT(3); PROJ_UNIT(4); PROJ_UNIT(5);
+      PROJ_UNIT(6); PROJ_UNIT(7); PROJ_UNIT(8); PROJ_UNIT(9); PROJ_UNIT(10); PROJ_UNIT(11);
 #undef PROJ_UNIT
       MLP_STAMP(1);
       {                       // the last tile's chunk
