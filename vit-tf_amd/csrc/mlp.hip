@@ -1,36 +1,36 @@
-// Fused transformer MLP for D = 384 with the LayerNorm that follows it:
-//     x += fc2( gelu_erf( fc1(h) + b1 ) ) + b2 ;   h_next = LayerNorm(x; g, b)
+// The tail of a ViT-S block (D = 384) in one launch, and the MLP alone:
+//     vittf_block_tail:  x' = x + a . Wp^T + bp ;  x += fc2( gelu_erf( fc1( LayerNorm(x'; g2, b2) ) + b1 ) ) + b2 ... i.e.
+//                        x := x' + MLP(norm2(x')) ;  h_next = LayerNorm(x; g, b)            (a = the attention output)
+//     vittf_mlp_fused:   x += fc2( gelu_erf( fc1(h) + b1 ) ) + b2 ;  h_next = LayerNorm(x; g, b)     (h = norm2's output)
 //
-// Replaces Mlp.forward + the residual add of the upstream DINO block and the next block's norm1 (reached through
-// model(...), infer.py:177).  The two-GEMM path writes the [rows][4D] hidden activation to HBM and reads it back -- 806 MB
-// per 32-slice batch, a third of the GEMM class's traffic -- and its fc2 kernel waits for that stream;
-// here the hidden activation never leaves the registers and the only streams are the weights, which every CU reads from
-// L2 at the same time (2.36 MB per layer), and one pass over h / x.
+// Replaces Attention.proj, both residual adds, norm2, Mlp.forward of the upstream DINO block and the next block's norm1
+// (reached through model(...), infer.py:177).  As three GEMM launches these moved 15.4 KB per row of the residual stream
+// (the fp32 rows twice in and out, the [rows][4D] hidden activation out and in, norm2's output out and in); here a row's
+// 4.6 KB -- a in, x in, x out, h out -- are all that reaches HBM, and the only other stream is the weights, which every CU
+// reads from L2 (2.65 MB per layer).
 //
-// Machine mapping (gfx950; round 3 -- the round-1 kernel of this file had the same data flow but ran its phases one after
-// the other: 0.66 ms per 32 slices against 0.44 for the two GEMMs; this one 0.36):
-//   * workgroup = 4 waves = 128 rows, ONE wave per SIMD with the whole 512-entry register file, persistent over row tiles.
-//     Both products are computed transposed (weights = MFMA A operand, activations = B operand, a lane owns one row): a
-//     wave keeps its 32 rows' LayerNorm output as 24 B operands (96 registers) and the full 384-wide output as 12
-//     accumulator tiles (192), so the fc1 accumulator tile -- bias as its initial value, GELU applied, converted pairwise
-//     to 16 bit -- IS the B operand of fc2 (k order 16 s + 8 (j >> 2) + 4 h + (j & 3): the host stores W2's hidden dim in
-//     that order) and a row's LayerNorm statistics never leave its wave.
-//   * the hidden dim is walked in units of 32: unit u costs 24 MFMAs for fc1 (one accumulator chain over K = 384) and 24
-//     for fc2 (12 output tiles x 2 k steps).  The weights arrive as a STREAM of 24 KB images, one per unit and product,
-//     packed by the host in exactly the order and LDS layout they are consumed in (weights.pack_mlp_weights): every LDS-DMA
-//     piece is 1 KB of contiguous memory.  Six ring slots, five units requested ahead, one barrier per unit, counted vmcnt.
+// Machine mapping (gfx950; DESIGN.md section 4 "Block tail" has the measurements behind every choice):
+//   * workgroup = 4 waves = 128 rows, ONE wave per SIMD with the whole 512-entry register file, persistent; tiles are handed
+//     out by a counter.  All products are computed transposed (weights = MFMA A operand from LDS, activations = B operand
+//     from registers, a lane owns one row): the projection's 12 accumulator tiles (192 registers) become x', norm2 runs in
+//     them and leaves fc1's 24 B operands (96 registers; k order = register order, the host packs W1 to match), the fc1
+//     accumulator tile -- bias as its initial value, GELU applied, converted pairwise to 16 bit -- IS the B operand of fc2
+//     (W2's hidden dim packed to match), fc2 accumulates on top of x', and a row's LayerNorm statistics never leave its wave.
+//   * work is cut into UNITS of 24 MFMAs: 12 projection units (one output tile each over K = 384), then 48 fc1 units (32
+//     hidden units over K = 384, one accumulator chain) interleaved with 48 fc2 units (12 output tiles x 2 k steps), fc1
+//     two hidden units ahead.  The weights arrive as a STREAM of 24 KB images, one per unit, packed by the host in exactly
+//     the order and LDS layout they are consumed in (weights.pack_block_tail_weights): every LDS-DMA piece is 1 KB of
+//     contiguous memory.  Five ring slots, four units requested ahead, one barrier per unit, counted vmcnt.
 //   * software pipeline, pinned per MFMA gap (one wave per SIMD: nothing else fills the gaps): the 24 A fragments of a
-//     unit are read through 8 fragment registers refilled in place right behind the MFMA that used them (the reads run 8
-//     MFMAs ahead, across unit boundaries); fc1 runs two hidden units ahead of fc2 and the GELU of the unit in between is
-//     cut into thirds of a value per gap over both (a one-wave SIMD hides about 24 issue cycles beside an MFMA, a whole
-//     value is 46); the six DMA pieces a wave issues per unit sit behind every fourth MFMA.
-//   * between two tiles: drain, then per output tile the fp32 residual comes in and the sum goes out THROUGH LDS (a lane
-//     owns a row, so direct accesses would be 32-byte runs, which a CU's memory path takes at 7 bytes per cycle; through
-//     the staging space they are 128-byte runs), the two-pass LayerNorm runs in the same registers (the other half of a
-//     row is in the lane 32 further on), h goes out the same way, and the next tile's h fragments are requested before all
-//     of that.  Measured per 128-row tile (tools/mlp_variants.py, stamps): 160 thousand cycles = 8 for the first six units
-//     + 105 for the other 90 (1170 per unit against 768 of bare MFMA: 173 LDS-DMA issue, 83 fragment reads, 141 GELU)
-//     + 45 for the epilogue, which moves its 590 KB per CU at the CU's share of the HBM rate (all CUs get there together).
+//     unit go through 8 fragment registers refilled in place right behind the MFMA that used them (the reads run 8 MFMAs
+//     ahead, across unit boundaries); the GELU of the fc1 tile between the two products is cut into thirds of a value per
+//     gap over both units of a pair (a one-wave SIMD hides about 24 issue cycles beside an MFMA, a whole value is 46); the
+//     six DMA pieces a wave issues per unit sit behind every fourth MFMA; the residual columns of output tile ot - 1 are
+//     folded in beside projection unit ot.
+//   * everything that crosses HBM in rows goes THROUGH LDS (6 KB of staging per wave): a lane owns a row, so direct accesses
+//     would be 32-byte runs, which a CU's memory path takes at 7 bytes per cycle; staged they are 128-byte runs.  Between two
+//     tiles: drain, request the next tile's fragments and first residual chunks (ahead of the stores: vmcnt retires in order),
+//     x = acc + b2 out, two-pass LayerNorm in the same registers (the other half of a row is in the lane 32 further on), h out.
 #include "vittf_common.h"
 
 #include <stdlib.h>
