@@ -318,7 +318,11 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
   };
   for (; t < ntiles; t += stride) {
     const bool more = t + stride < ntiles;
-    s16x8_t xf[SM_KS];
+    // the tile's dot products grow part by part (8 MFMAs behind every part's fragment reads): with all 48 behind the last
+    // part nothing new was requested for the length of that phase, once per tile -- 16 % of the tile time
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int p = 0; p < SM_FEW_PARTS; ++p) {
       // part p landed: of everything issued after it only the 4 pieces of part p + 1 (and, conservatively counted, an older
@@ -330,13 +334,23 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
       if (p + 2 < SM_FEW_PARTS) SM_STAGE_ROWS(t, p + 2)
       else if (more) SM_STAGE_ROWS(t + stride, p + 2 - SM_FEW_PARTS)
       const char* buf = ring + (p % 3) * SM_FEW_PART + tr_off;
+      s16x8_t xf[SM_FEW_ROWS / 16];
 #pragma unroll
       for (int s = 0; s < SM_FEW_ROWS / 16; ++s) {
         const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s) * 512));
         const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(buf + (16 * s + 4) * 512));
         s16x8_t x;
         x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
-        xf[(SM_FEW_ROWS / 16) * p + s] = x;
+        xf[s] = x;
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < SM_FEW_ROWS / 16; ++s4) {
+        const int s = (SM_FEW_ROWS / 16) * p + s4;
+        const int off = (s >> 2) * 4096 + (aoff0 ^ (32 * (s & 3)));
+        const s16x8_t qh = *reinterpret_cast<const s16x8_t*>(qbuf + off);
+        const s16x8_t ql = *reinterpret_cast<const s16x8_t*>(qbuf + SM_PART + off);
+        acc = mfma32<VITTF_FP16>(qh, xf[s4], acc);
+        acc = mfma32<VITTF_FP16>(ql, xf[s4], acc);
       }
       if (pend_v >= 0) {              // (wave-uniform) the previous tile's values 3 p .. 3 p + 2; the last part takes value 15
 #pragma unroll
@@ -346,17 +360,6 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
     if (pend_v >= 0) finish();
     const int64_t v = (int64_t)t * SM_VOX + wave * 32 + l31;
     pend_nv = (vnorm && v < nvox) ? vnorm[v] : 1.f;
-    f32x16_t acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < SM_KS; ++s) {
-      const int off = (s >> 2) * 4096 + (aoff0 ^ (32 * (s & 3)));
-      const s16x8_t qh = *reinterpret_cast<const s16x8_t*>(qbuf + off);
-      const s16x8_t ql = *reinterpret_cast<const s16x8_t*>(qbuf + SM_PART + off);
-      acc = mfma32<VITTF_FP16>(qh, xf[s], acc);
-      acc = mfma32<VITTF_FP16>(ql, xf[s], acc);
-    }
     pend = acc;
     pend_v = v;
   }
