@@ -208,6 +208,11 @@ def test_block_tail(gpu, dt, rows):
                                    _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h3), _lib.stream_ptr()))
     assert rel_fro(xd[:rows].double() - x0[:rows].to(gpu).double(), x2[:rows].double() - x0[:rows].to(gpu).double()) <= EPS[dt] / 2
     assert rel_fro(hout[:rows].float(), h3.float()) <= 2 * EPS[dt]
+    # without the LayerNorm on the way out: the same residual rows, nothing else written
+    x3 = x0.to(gpu)
+    _lib.check(lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
+                                    _lib.ptr(x3), rows, d, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.stream_ptr()))
+    assert torch.equal(x3, xd)
     assert lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
                                 _lib.ptr(xd), rows, 768, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.stream_ptr()) == -1
 
