@@ -1,6 +1,7 @@
 #!/bin/bash
 # Timing-only builds of the fused MLP kernel (csrc/mlp.hip, -DMLP_VARIANT=bits: 1 no weight DMA inside the units, 2 LDS-DMA
-# without the M0 save / restore, 4 no fragment refills, 8 no activation arithmetic), each as its own small shared object
+# WITH the M0 save / restore, 4 no fragment refills, 8 no activation arithmetic, 16 in-kernel stamps, 32 / 64 block tail:
+# projection units without the residual chunk requests / without folding them in), each as its own small shared object
 # under tools/micro/build/ -- never part of libvittf.so.  Results of variants other than 0 and 2 are wrong by construction.
 #   tools/mlp_variants.sh 0 1 2 4 8 ...     then on the GPU box: python tools/mlp_variants.py
 set -e

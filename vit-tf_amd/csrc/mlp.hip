@@ -106,7 +106,8 @@ __device__ unsigned long long g_mlp_stamps[4 /*workgroups*/][4 /*tiles*/][4 /*wa
 #else
 #define MLP_STAMP(k)
 #endif
-constexpr bool V_NO_DMA = MLP_VARIANT & 1, V_M0_KEEP = MLP_VARIANT & 2 /* here: save + restore M0 */, V_NO_REFILL = MLP_VARIANT & 4, V_NO_GELU = MLP_VARIANT & 8;
+constexpr bool V_NO_DMA = MLP_VARIANT & 1, V_M0_KEEP = MLP_VARIANT & 2 /* here: save + restore M0 */, V_NO_REFILL = MLP_VARIANT & 4, V_NO_GELU = MLP_VARIANT & 8,
+               V_NO_XREQ = MLP_VARIANT & 32 /* projection units: no residual chunk requests */, V_NO_XFOLD = MLP_VARIANT & 64 /* ... no staging / adds */;
 
 // an LDS-DMA piece that leaves M0 pointing at its destination (lds_dma16 saves and restores it: the restore waits until the
 // load has left the wave's instruction buffer).  hipcc keeps nothing in M0 in this kernel: tests/test_host_cpu.py checks
@@ -189,7 +190,7 @@ __device__ __forceinline__ void proj_unit(Stream& st, unsigned (&base)[4], s16x8
   for (int j = 0; j < 24; ++j) {
     xacc[OT] = mfma32<DT>(wf[j % NF], af[j], j == 0 ? bias_c : xacc[OT]);
     stream_gap<LAST>(st, base, wf, j, g_next, slot_free);
-    if constexpr (OT > 0) {
+    if constexpr (OT > 0 && !V_NO_XFOLD) {
       if (j < 4) {
         *(lds_w4_ptr)(stg_rd + j * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[(OT - 1) % XA][j]);
       } else if (j >= 6 && j < 10) {
@@ -199,7 +200,7 @@ __device__ __forceinline__ void proj_unit(Stream& st, unsigned (&base)[4], s16x8
         xacc[OT - 1][r] += xv[r >> 2][r & 3];
         xacc[OT - 1][r + 1] += xv[r >> 2][(r & 3) + 1];
       }
-      if constexpr (REQ)
+      if constexpr (REQ && !V_NO_XREQ)
         if (j >= 18 && j < 22)
           xi[(OT - 1) % XA][j - 18] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo + (OT - 1 + XA) * 128, (j - 18) * 8 * (D * 4), 0);
     }
