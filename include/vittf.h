@@ -213,7 +213,8 @@ int vittf_mlp_fused(const void* h, const void* w_packed, const float* b1, const 
  * model(...), infer.py:177).  attn_out: h16 [rows][D] (vittf_attention's output); w_packed: h16 [108][12288], one block of
  * vittf_vit_weights.tail_packed.  The fp32 residual rows are read once and written once, and neither x' nor norm2's output
  * nor the hidden activation reaches HBM.  Same result as vittf_gemm_residual_ln (proj) + vittf_mlp_fused up to fp32
- * summation order. */
+ * summation order.  attn_out, w_packed, x and h_out must be 16-byte aligned (VITTF_ERR_INVALID_ARG otherwise); D != 384:
+ * VITTF_ERR_INVALID_ARG (use the GEMM entries). */
 int vittf_block_tail(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g, const float* ln2_b,
                      const float* b1, const float* b2, float* x, int64_t rows, int32_t d, int32_t dtype, const float* ln_g,
                      const float* ln_b, float ln_eps, void* h_out, void* stream);

@@ -208,6 +208,9 @@ def test_block_tail(gpu, dt, rows):
                                    _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h3), _lib.stream_ptr()))
     assert rel_fro(xd[:rows].double() - x0[:rows].to(gpu).double(), x2[:rows].double() - x0[:rows].to(gpu).double()) <= EPS[dt] / 2
     assert rel_fro(hout[:rows].float(), h3.float()) <= 2 * EPS[dt]
+    # misaligned rows are refused, not mis-read (every access is 16 bytes wide)
+    assert lib.vittf_block_tail(C.c_void_p(ad.data_ptr() + 2), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
+                                _lib.ptr(xd), rows, d, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.stream_ptr()) == -1
     # without the LayerNorm on the way out: the same residual rows, nothing else written
     x3 = x0.to(gpu)
     _lib.check(lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),

@@ -644,6 +644,8 @@ static int mlp_launch(bool tail, const void* a, const void* w_packed, const floa
                       const float* ln_b, float ln_eps, void* h_out, void* stream) {
   const int64_t tiles = (rows + 127) / 128;
   if (tiles > 0x7fffffff) return VITTF_ERR_INVALID_ARG;
+  // 16-byte accesses everywhere (LDS-DMA pieces, buffer loads / stores of whole 128-byte runs)
+  if ((((uintptr_t)a | (uintptr_t)w_packed | (uintptr_t)x | (uintptr_t)h_out) & 15) != 0) return VITTF_ERR_INVALID_ARG;
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
