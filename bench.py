@@ -385,6 +385,16 @@ def main():
         'whole_vit_tflops': round(sum(flops.values()) / (vit_ms * 1e-3) / 1e12, 2) if vit_ms > 0 else 0.0,
     }
 
+    # the second-largest kernel since round 3: everything behind the attention of a block in one launch (csrc/mlp.hip)
+    roofline_tail = None
+    if prof['mlp'][1] > 0 and prof['mlp'][0] > 0:
+        t_ms, t_n = prof['mlp']
+        t_ach = flops['mlp'] / (t_ms * 1e-3) / 1e12
+        roofline_tail = {'bound': 'mfma', 'achieved': round(t_ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(t_ach / peak, 4),
+                         'traffic': None, 'kernel': kernels['mlp'], 'launches': int(t_n), 'avg_launch_ms': round(t_ms / t_n, 4),
+                         'flop_per_launch': flops['mlp'] / t_n,
+                         'note': 'events around its launches in one extra untimed step; PMC of the kernel: profiles/r03d_block_tail_pmc.txt'}
+
     if rank == 0:
         out = {
             'metric': f'slices/sec ({"ViT-S/8" if args.arch == "vits8" else "ViT-B/8"}, {args.workload}^3 vol: feature volume + '
@@ -402,6 +412,7 @@ def main():
                        'dist_backend': backend},
             'roofline': roofline,
             'roofline_similarity': roofline_sim,
+            'roofline_block_tail': roofline_tail,
             'similarity': {'ms': round(sim_ms, 3), 'queries': N_QUERIES,
                            'mvoxel_sim_per_s': round(nvox * N_QUERIES / 1e6 / (sim_ms * 1e-3), 1),
                            'mvoxel_per_s': round(nvox / 1e6 / (sim_ms * 1e-3), 1),
