@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITTF_ABI_VERSION 3
+#define VITTF_ABI_VERSION 4
 
 typedef enum vittf_status {
   VITTF_OK = 0,
@@ -202,9 +202,13 @@ int vittf_ln_gemm(const float* x, const float* ln_g, const float* ln_b, float ln
  * [rows][4D] hidden activation, and -- when ln_g / ln_b / h_out are given -- h_out[rows][D] (h16) = LayerNorm(x_new; ln_g,
  * ln_b, ln_eps) on the way out (the next block's norm1).  h: h16 [rows][D] (LayerNorm2 output); w_packed: h16 [96][12288], one
  * block of vittf_vit_weights.mlp_packed.  Same result as vittf_gemm(BIAS_GELU) + vittf_gemm_residual_ln up to the fp32
- * summation order of fc2 (the hidden activation is identical: both round it once to h16). */
+ * summation order of fc2 (the hidden activation is identical: both round it once to h16).
+ * tile_counter: vittf_block_tail_workspace_bytes() bytes of caller-owned device memory, 4-byte aligned, private to this
+ * call until it has finished on `stream` (the persistent workgroups hand out 128-row tiles through it; the call zeroes it
+ * on `stream` itself).  Calls that may run concurrently -- two streams -- need one counter each. */
 int vittf_mlp_fused(const void* h, const void* w_packed, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
-                    int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* stream);
+                    int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* tile_counter,
+                    void* stream);
 
 /* Everything behind the attention of one block for D == 384, in one launch:
  *   x' = x + attn_out . Wp^T + proj_b ;  x_new = x' + fc2(gelu_erf(fc1(LayerNorm(x'; ln2)) + b1)) + b2 ;  x := x_new ;
@@ -214,10 +218,12 @@ int vittf_mlp_fused(const void* h, const void* w_packed, const float* b1, const 
  * vittf_vit_weights.tail_packed.  The fp32 residual rows are read once and written once, and neither x' nor norm2's output
  * nor the hidden activation reaches HBM.  Same result as vittf_gemm_residual_ln (proj) + vittf_mlp_fused up to fp32
  * summation order.  attn_out, w_packed, x and h_out must be 16-byte aligned (VITTF_ERR_INVALID_ARG otherwise); D != 384:
- * VITTF_ERR_INVALID_ARG (use the GEMM entries). */
+ * VITTF_ERR_INVALID_ARG (use the GEMM entries).  tile_counter: as for vittf_mlp_fused (caller-owned, one per concurrent
+ * call; inside vittf_vit_k_features it lives in the engine workspace). */
+size_t vittf_block_tail_workspace_bytes(void);
 int vittf_block_tail(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g, const float* ln2_b,
                      const float* b1, const float* b2, float* x, int64_t rows, int32_t d, int32_t dtype, const float* ln_g,
-                     const float* ln_b, float ln_eps, void* h_out, void* stream);
+                     const float* ln_b, float ln_eps, void* h_out, void* tile_counter, void* stream);
 
 /* Multi-head self-attention over `batch` independent sequences of `tokens` rows.
  * qkv h16 [batch*tokens][3D] with columns [q | k | v], heads of 64 concatenated inside each third

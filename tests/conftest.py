@@ -23,6 +23,20 @@ def pytest_sessionstart(session):
                        check=True, stdout=subprocess.DEVNULL)
 
 
+@pytest.fixture(scope='session', autouse=True)
+def oracle_threads():
+    """ONE place that sizes torch's CPU thread pool for the oracle: the cores this process may really use (affinity mask
+    capped by the cgroup quota, at most 16 -- bench.host_cores).  A GPU box reports 256 CPUs to os.cpu_count() for a 16-CPU
+    share, and a pool of that size makes every CPU reference in the session several times slower (GPUTEST_r03: the suite
+    hit the driver's 900 s limit).  No test sets the thread count itself."""
+    import torch
+    from bench import host_cores
+    before = torch.get_num_threads()
+    torch.set_num_threads(host_cores())
+    yield host_cores()
+    torch.set_num_threads(before)
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

@@ -33,7 +33,6 @@ def vits8(gpu):
 
 @pytest.fixture(scope='module')
 def oracle_vits8(vits8):
-    torch.set_num_threads(min(16, len(__import__('os').sched_getaffinity(0))))
     return dino_vit.build_vit('vits8', vits8[0])
 
 
@@ -87,7 +86,7 @@ def _whole_volume_checks(gpu, vits8, oracle, vol, windows, tol=TOL):
 def test_config1_256_whole_volume(gpu, vits8, oracle_vits8):
     """BASELINE configs[1]: every slice of the 256^3 torus volume (2x nearest up-sampling to 512 x 512)."""
     vol, _ = vt.synthetic_volume('torus_filled', 256, 0.1, 0)
-    _whole_volume_checks(gpu, vits8, oracle_vits8, vol, {'z': 31, 'y': 40, 'x': 22})
+    _whole_volume_checks(gpu, vits8, oracle_vits8, vol, {'y': 40})       # one window against the oracle (z / x: configs[2] below)
 
 
 @pytest.fixture(scope='module')
@@ -113,7 +112,6 @@ def test_config3_vitb8_fp8_attention_512_whole_volume(gpu, ct512):
     (5e-2 relative Frobenius: 3-bit mantissas on q, k, v and P in 11 attention layers; measured 1.5e-2), and the same
     window with 16-bit attention at the contract's 1e-3."""
     sd = vt.synthetic_state_dict('vitb8', 2)
-    torch.set_num_threads(min(16, len(__import__('os').sched_getaffinity(0))))
     oracle = dino_vit.build_vit('vitb8', sd)
     model8 = vt.HipViT(sd, 'vitb8', 'fp16', device=gpu, attention='fp8')
     feats = _whole_volume_checks(gpu, (sd, model8), oracle, ct512[0], {'y': 29}, tol=5e-2)
@@ -273,7 +271,6 @@ def test_config3_768_feature_volume_5x1024_queries(gpu, ct512):
     feat = F.normalize(feat, dim=0).half()
     got = vt.compute_similarities(vol, feat, ann)
     assert vt._lib.kernel_name('similarity') == 'sim_mfma_kernel<F 768>'
-    torch.set_num_threads(os.cpu_count() or 8)
     ref = osim.similarity_maps(tuple(vol.shape), feat.float(), ann)
     for k in ann:
         assert got[k].shape == (256, 256, 256) and got[k].dtype == torch.uint8

@@ -108,6 +108,12 @@ def test_gemm_rejects_bad_shapes(gpu):
     assert lib.vittf_gemm(None, _lib.ptr(t), _lib.ptr(f), _lib.ptr(t), 4, 128, 64, 0, 0, 1, _lib.stream_ptr()) == -1
 
 
+# Rows behind the last valid one in x / h_out of the fused kernels: a partial tile's stores carry row offsets of 8, 16 and 24
+# rows in the buffer instructions' soffset operand; on gfx950 voffset + soffset IS range-checked against the descriptor (the
+# rows=128*300+77 case puts such a store on a guard row and leaves it untouched) -- 32 guard rows let every shape detect it.
+GUARD_ROWS = 32
+
+
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('rows,with_ln', [(1, True), (130, True), (4097, False), (4097, True), (128 * 300 + 77, True)])
 def test_mlp_fused(gpu, dt, rows, with_ln):
@@ -123,17 +129,19 @@ def test_mlp_fused(gpu, dt, rows, with_ln):
     w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
     b2 = 0.3 * torch.randn(d, generator=g)
     lg, lb = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
-    x0 = torch.randn(rows + 2, d, generator=g) * 3
+    x0 = torch.randn(rows + GUARD_ROWS, d, generator=g) * 3
+    ctr = torch.full((1,), 12345, dtype=torch.int32, device=gpu)      # caller-owned tile counter (zeroed by the call itself)
+    assert lib.vittf_block_tail_workspace_bytes() <= ctr.numel() * 4
     hd, w1d, b1d, w2d, b2d, lgd, lbd = (t.to(gpu) for t in (h, w1, b1, w2, b2, lg, lb))
     hid = F.gelu(hd.double() @ w1d.double().t() + b1d.double()).to(TDT[dt]).double()
     ref = (x0[:rows].to(gpu).double() + hid @ w2d.double().t() + b2d.double()).cpu()
     wpk = vt.weights.pack_mlp_weights(w1d[None], w2d[None])[0].contiguous()
     assert wpk.shape == (96, 12288)
     xd = x0.to(gpu)
-    hn = torch.full((rows + 2, d), 7.0, dtype=TDT[dt], device=gpu)
+    hn = torch.full((rows + GUARD_ROWS, d), 7.0, dtype=TDT[dt], device=gpu)
     _lib.check(lib.vittf_mlp_fused(_lib.ptr(hd), _lib.ptr(wpk), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(xd), rows, d, _lib.DTYPES[dt],
                                    _lib.ptr(lgd) if with_ln else None, _lib.ptr(lbd) if with_ln else None, 1e-6,
-                                   _lib.ptr(hn) if with_ln else None, _lib.stream_ptr()))
+                                   _lib.ptr(hn) if with_ln else None, _lib.ptr(ctr), _lib.stream_ptr()))
     got = xd.cpu().double()
     assert torch.equal(got[rows:], x0[rows:].double()), 'wrote past the last row'
     # a hidden unit whose fp32 pre-activation sits on a rounding boundary may round the other way than in fp64
@@ -154,7 +162,7 @@ def test_mlp_fused(gpu, dt, rows, with_ln):
         assert ((hn[:rows].cpu().double() - want).abs() <= 2 * EPS[dt] * (1 + want.abs())).all()
         assert torch.allclose(hn[:rows].float(), h2.float(), rtol=0, atol=4 * EPS[dt] * float(want.abs().max()))
     assert lib.vittf_mlp_fused(_lib.ptr(hd), _lib.ptr(wpk), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(xd), rows, 768, _lib.DTYPES[dt],
-                               None, None, 1e-6, None, _lib.stream_ptr()) == -1
+                               None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()) == -1
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
@@ -175,7 +183,8 @@ def test_block_tail(gpu, dt, rows):
     b2 = 0.3 * torch.randn(d, generator=g)
     g2, e2 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
     g1, e1 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
-    x0 = torch.randn(rows + 2, d, generator=g) * 3
+    x0 = torch.randn(rows + GUARD_ROWS, d, generator=g) * 3
+    ctr = torch.full((1,), 12345, dtype=torch.int32, device=gpu)      # caller-owned tile counter (zeroed by the call itself)
     ad, wpd, bpd, w1d, b1d, w2d, b2d, g2d, e2d, g1d, e1d = (t.to(gpu) for t in (a, wp, bp, w1, b1, w2, b2, g2, e2, g1, e1))
     # fp64 reference
     x1 = x0[:rows].to(gpu).double() + ad.double() @ wpd.double().t() + bpd.double()
@@ -185,10 +194,10 @@ def test_block_tail(gpu, dt, rows):
     wpk = vt.weights.pack_block_tail_weights(wpd[None], w1d[None], w2d[None])[0].contiguous()
     assert wpk.shape == (108, 12288)
     xd = x0.to(gpu)
-    hout = torch.full((rows + 2, d), 7.0, dtype=TDT[dt], device=gpu)
+    hout = torch.full((rows + GUARD_ROWS, d), 7.0, dtype=TDT[dt], device=gpu)
     _lib.check(lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
                                     _lib.ptr(xd), rows, d, _lib.DTYPES[dt], _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(hout),
-                                    _lib.stream_ptr()))
+                                    _lib.ptr(ctr), _lib.stream_ptr()))
     got = xd.cpu().double()
     assert torch.equal(got[rows:], x0[rows:].double()), 'wrote past the last row'
     assert (hout[rows:].float() == 7.0).all(), 'wrote past the last row of h'
@@ -205,19 +214,66 @@ def test_block_tail(gpu, dt, rows):
     mpk = vt.weights.pack_mlp_weights(w1d[None], w2d[None])[0].contiguous()
     h3 = torch.zeros(rows, d, dtype=TDT[dt], device=gpu)
     _lib.check(lib.vittf_mlp_fused(_lib.ptr(h2), _lib.ptr(mpk), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(x2), rows, d, _lib.DTYPES[dt],
-                                   _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h3), _lib.stream_ptr()))
+                                   _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h3), _lib.ptr(ctr), _lib.stream_ptr()))
     assert rel_fro(xd[:rows].double() - x0[:rows].to(gpu).double(), x2[:rows].double() - x0[:rows].to(gpu).double()) <= EPS[dt] / 2
     assert rel_fro(hout[:rows].float(), h3.float()) <= 2 * EPS[dt]
     # misaligned rows are refused, not mis-read (every access is 16 bytes wide)
     assert lib.vittf_block_tail(C.c_void_p(ad.data_ptr() + 2), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
-                                _lib.ptr(xd), rows, d, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.stream_ptr()) == -1
+                                _lib.ptr(xd), rows, d, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()) == -1
     # without the LayerNorm on the way out: the same residual rows, nothing else written
     x3 = x0.to(gpu)
     _lib.check(lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
-                                    _lib.ptr(x3), rows, d, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.stream_ptr()))
+                                    _lib.ptr(x3), rows, d, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()))
     assert torch.equal(x3, xd)
     assert lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
-                                _lib.ptr(xd), rows, 768, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.stream_ptr()) == -1
+                                _lib.ptr(xd), rows, 768, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()) == -1
+
+
+def test_block_tail_two_streams_caller_owned_counters(gpu):
+    """The library keeps no state of its own for the block tail: two calls in flight at once on two streams, each with its OWN
+    tile counter (caller memory, vittf_block_tail_workspace_bytes()), write the same bits as the same calls one after the
+    other; a missing or misaligned counter is refused."""
+    lib = _lib.load()
+    d, dt = 384, 'fp16'
+    rows = (128 * 700 + 9, 128 * 650 + 100)                      # ~2.7 rounds of persistent workgroups each: they do overlap
+    g = gen(77)
+    wp = (torch.randn(d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(gpu)
+    w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(gpu)
+    w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt]).to(gpu)
+    wpk = vt.weights.pack_block_tail_weights(wp[None], w1[None], w2[None])[0].contiguous()
+    vecs = [(0.3 * torch.randn(n, generator=g)).to(gpu) for n in (d, d, d, 4 * d, d, d, d)]      # bp, g2, e2, b1, b2, g1, e1
+    vecs[1] += 1.0; vecs[5] += 1.0
+    bp, g2, e2, b1, b2, g1, e1 = vecs
+    assert lib.vittf_block_tail_workspace_bytes() == 4
+    a = [torch.randn(r, d, generator=g).to(TDT[dt]).to(gpu) for r in rows]
+    x0 = [(3 * torch.randn(r, d, generator=g)).to(gpu) for r in rows]
+
+    def call(i, x, h, ctr, stream):
+        return lib.vittf_block_tail(_lib.ptr(a[i]), _lib.ptr(wpk), _lib.ptr(bp), _lib.ptr(g2), _lib.ptr(e2), _lib.ptr(b1), _lib.ptr(b2),
+                                    _lib.ptr(x), rows[i], d, _lib.DTYPES[dt], _lib.ptr(g1), _lib.ptr(e1), 1e-6, _lib.ptr(h),
+                                    ctr, C.c_void_p(stream.cuda_stream))
+    ctrs = torch.zeros(2, 64, dtype=torch.int32, device=gpu)      # two counters, 256 bytes apart
+    cur = torch.cuda.current_stream()
+    seq = []
+    for i in range(2):
+        x, h = x0[i].clone(), torch.empty(rows[i], d, dtype=TDT[dt], device=gpu)
+        _lib.check(call(i, x, h, _lib.ptr(ctrs[i]), cur))
+        seq.append((x, h))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    par = [(x0[i].clone(), torch.empty(rows[i], d, dtype=TDT[dt], device=gpu)) for i in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(3):                                          # back to back on each stream: counters are re-zeroed per call
+        for i in range(2):
+            if rep:
+                with torch.cuda.stream(streams[i]):
+                    par[i][0].copy_(x0[i])
+            _lib.check(call(i, par[i][0], par[i][1], _lib.ptr(ctrs[i]), streams[i]))
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(par[i][0], seq[i][0]) and torch.equal(par[i][1], seq[i][1]), f'stream {i}'
+    assert call(0, par[0][0], par[0][1], None, cur) == -1
+    assert call(0, par[0][0], par[0][1], C.c_void_p(ctrs.data_ptr() + 2), cur) == -1
 
 
 # ------------------------------------------------------------------------------------------ attention

@@ -84,23 +84,30 @@ def test_compute_qkv_api(gpu, golden_dir, dt):
     assert pooled['k'].shape == ref.shape and rel_fro(pooled['k'], ref) <= TOL[dt][0]
 
 
-@pytest.mark.parametrize('dt', ['fp16', 'bf16'])
-def test_vits8_full_size_slices(gpu, dt):
-    """ViT-S/8, 512 x 512 images (N = 4097), 12 blocks: two z-slices of a noisy 64^3 torus vs the CPU fp32 oracle."""
+@pytest.fixture(scope='module')
+def vits8_torus_oracle():
+    """The CPU fp32 oracle on z-slices 20 and 33 of the noisy 64^3 torus (BASELINE configs[0]'s volume) at 512 x 512, N = 4097:
+    computed ONCE per session and shared by the fp16 and the bf16 case (a ViT-S/8 slice is seconds of host time)."""
     sd = vt.synthetic_state_dict('vits8', 0)
-    model = vt.HipViT(sd, 'vits8', dt)
     vol, _ = vt.synthetic_volume('torus_filled', 64, 0.1, 0)
     vol = vol.float()
+    slices = (20, 33)
+    oracle = dino_vit.build_vit('vits8', sd)
+    imgs = ofv.normalized_slices(vol, 'z')[list(slices)]
+    with torch.no_grad():
+        ref = ofv.k_tokens(oracle, torch.nn.functional.interpolate(imgs, size=(512, 512), mode='nearest'))[:, 1:]
+    return sd, vol, slices, ref
+
+
+@pytest.mark.parametrize('dt', ['fp16', 'bf16'])
+def test_vits8_full_size_slices(gpu, vits8_torus_oracle, dt):
+    """ViT-S/8, 512 x 512 images (N = 4097), 12 blocks: two z-slices of a noisy 64^3 torus vs the CPU fp32 oracle."""
+    sd, vol, slices, ref = vits8_torus_oracle
+    model = vt.HipViT(sd, 'vits8', dt)
     im_sz, feat_out = vt.sizing((64, 64, 64), 64, 8)
     assert im_sz == (512, 512, 512) and feat_out == (64, 64, 64)
     dvol = vt.DeviceVolume(vol, gpu)
-    slices = (20, 33)
     got = torch.stack([vt.k_slices(model, dvol, 'z', im_sz, s, s + 1)[0] for s in slices]).cpu()   # (2, 4096, 384)
-    oracle = dino_vit.build_vit('vits8', sd)
-    imgs = ofv.normalized_slices(vol, 'z')[list(slices)]
-    torch.set_num_threads(os.cpu_count() or 8)
-    with torch.no_grad():
-        ref = ofv.k_tokens(oracle, torch.nn.functional.interpolate(imgs, size=(512, 512), mode='nearest'))[:, 1:]
     e = rel_fro(got, ref)
     print(f'vits8 N=4097 {dt}: rel fro {e:.3e}, max abs {max_abs(got, ref):.3e}, ref rms {float(ref.pow(2).mean().sqrt()):.3f}')
     assert torch.isfinite(got.float()).all()
@@ -112,11 +119,14 @@ def test_vits8_outlier_channels_full_size(gpu):
     channels, x50 LayerNorm gains, one head whose logits reach +-60 inside a row, one with logits up to ~130) instead of the
     benign Gaussian ones every other parity test uses: ViT-S/8 at N = 4097, default dtype, against the CPU fp32 oracle.
     Finite everywhere, and the lazy-maximum attention kernel demonstrably took its overflow branch (the first key tile's
-    maximum is far below what later keys reach in the planted head).  Measured 1.06e-3 -- twice the 5.3e-4 of the benign
-    weights and a hair above the contract's 1e-3, whatever the planted logits (+-60 and +-90 give the same figure): with
-    massive channels a LayerNorm's statistics ARE those channels, so the 2^-11 relative rounding they carry through the 16-bit
-    operands becomes a common-mode relative error of every channel of every later layer.  That is a property of 16-bit
-    operands (the reference's own fp16 autocast included), not of a kernel; the bound here is 1.5e-3 and says so."""
+    maximum is far below what later keys reach in the planted head).
+
+    The bound is tied to a MEASUREMENT, not to a guess: the same oracle module, same weights, same slice, run the way the
+    unmodified reference runs on a GPU (infer.py:173, 308-309: stock PyTorch-ROCm ops under torch.autocast(fp16), hooked
+    tensor rounded to fp16) gives e_stock against the same fp32 CPU result; the HIP path must be within
+    max(1e-3, 1.05 x e_stock).  With massive channels a LayerNorm's statistics ARE those channels, so the 2^-11 relative
+    rounding they carry through 16-bit GEMM operands becomes a common-mode relative error of every later layer -- for any
+    16-bit implementation, the reference's own included; both figures are printed."""
     sd = vt.synthetic_state_dict('vits8', 0, outliers=True)
     model = vt.HipViT(sd, 'vits8', 'fp16')
     vol, _ = vt.synthetic_volume('torus_filled', 64, 0.1, 0)
@@ -128,16 +138,18 @@ def test_vits8_outlier_channels_full_size(gpu):
     got = vt.k_slices(model, dvol, 'z', im_sz, 20, 21)[0].cpu()            # (4096, 384)
     rescales = int(lib.vittf_attention_rescale_count(1))
     oracle = dino_vit.build_vit('vits8', sd)
-    imgs = ofv.normalized_slices(vol, 'z')[[20]]
-    torch.set_num_threads(os.cpu_count() or 8)
+    imgs = torch.nn.functional.interpolate(ofv.normalized_slices(vol, 'z')[[20]], size=(512, 512), mode='nearest')
     with torch.no_grad():
-        ref = ofv.k_tokens(oracle, torch.nn.functional.interpolate(imgs, size=(512, 512), mode='nearest'))[0, 1:]
-    e = rel_fro(got, ref)
-    print(f'vits8 N=4097 fp16, outlier weights: rel fro {e:.3e}, max abs {max_abs(got, ref):.3e}, ref rms '
-          f'{float(ref.pow(2).mean().sqrt()):.3f}, overflow branch taken {rescales} times')
-    assert torch.isfinite(got.float()).all()
+        ref = ofv.k_tokens(oracle, imgs)[0, 1:]
+        with torch.autocast('cuda', dtype=torch.float16):                   # what the unmodified reference does on this GPU
+            stock = ofv.k_tokens(oracle.to(gpu), imgs.to(gpu))[0, 1:].half().cpu()
+    e, e_stock = rel_fro(got, ref), rel_fro(stock, ref)
+    print(f'vits8 N=4097 fp16, outlier weights: rel fro {e:.3e} (stock PyTorch-ROCm fp16 autocast on the same weights and slice: '
+          f'{e_stock:.3e}), max abs {max_abs(got, ref):.3e}, ref rms {float(ref.pow(2).mean().sqrt()):.3f}, overflow branch taken '
+          f'{rescales} times')
+    assert torch.isfinite(got.float()).all() and torch.isfinite(stock.float()).all()
     assert rescales > 0
-    assert e <= 1.5e-3
+    assert e <= max(1e-3, 1.05 * e_stock)
 
 
 def test_batching_and_sharding_do_not_change_bits(gpu):
@@ -337,7 +349,6 @@ def test_vitb8_full_size_slice(gpu):
     im_sz, _ = vt.sizing((64, 64, 64), 64, 8)
     oracle = dino_vit.build_vit('vitb8', sd)
     imgs = ofv.normalized_slices(vol, 'y')[[31]]
-    torch.set_num_threads(min(16, os.cpu_count() or 8))
     with torch.no_grad():
         ref = ofv.k_tokens(oracle, torch.nn.functional.interpolate(imgs, size=(512, 512), mode='nearest'))[:, 1:]
     for dt in ('fp16', 'bf16'):
@@ -366,7 +377,6 @@ def test_fos128_long_sequence(gpu):
     im_sz = (1024, 1024, 16)
     oracle = dino_vit.build_vit(arch, sd)
     imgs = ofv.normalized_slices(vol, 'z')[[1]]
-    torch.set_num_threads(min(16, os.cpu_count() or 8))
     with torch.no_grad():
         ref = ofv.k_tokens(oracle, torch.nn.functional.interpolate(imgs, size=(1024, 1024), mode='nearest'))[:, 1:]
     model = vt.HipViT(sd, arch, 'fp16')

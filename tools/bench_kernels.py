@@ -150,8 +150,9 @@ def main():
         x = torch.zeros(rows, d, device=dev)
         lg = torch.ones(d, device=dev); lb = torch.zeros(d, device=dev)
         hn = torch.empty(rows, d, dtype=TDT[dt], device=dev)
+        ctr = torch.zeros(1, dtype=torch.int32, device=dev)
         ms = timeit(lambda: _lib.check(lib.vittf_mlp_fused(_lib.ptr(hh), _lib.ptr(wpk), _lib.ptr(b1), _lib.ptr(b2), _lib.ptr(x), rows, d,
-                                                            _lib.DTYPES[dt], _lib.ptr(lg), _lib.ptr(lb), 1e-6, _lib.ptr(hn), _lib.stream_ptr())))
+                                                            _lib.DTYPES[dt], _lib.ptr(lg), _lib.ptr(lb), 1e-6, _lib.ptr(hn), _lib.ptr(ctr), _lib.stream_ptr())))
         fl = 4 * rows * d * 4 * d
         print(f'fused mlp + ln [{rows}x{d}]: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({ms * 32 / batch:.4f} ms per 32 slices)')
     if 'tail' in what:
@@ -164,9 +165,10 @@ def main():
         x = torch.zeros(rows, d, device=dev)
         lg = torch.ones(d, device=dev); lb = torch.zeros(d, device=dev)
         hn = torch.empty(rows, d, dtype=TDT[dt], device=dev)
+        ctr = torch.zeros(1, dtype=torch.int32, device=dev)
         ms = timeit(lambda: _lib.check(lib.vittf_block_tail(_lib.ptr(aa), _lib.ptr(tpk), _lib.ptr(bp), _lib.ptr(lg), _lib.ptr(lb), _lib.ptr(b1),
                                                              _lib.ptr(b2), _lib.ptr(x), rows, d, _lib.DTYPES[dt], _lib.ptr(lg), _lib.ptr(lb), 1e-6,
-                                                             _lib.ptr(hn), _lib.stream_ptr())))
+                                                             _lib.ptr(hn), _lib.ptr(ctr), _lib.stream_ptr())))
         fl = 18 * rows * d * d
         print(f'block tail (proj + ln + mlp + ln) [{rows}x{d}]: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({ms * 32 / batch:.4f} ms per 32 slices)')
     if 'ln' in what:

@@ -22,6 +22,7 @@ def main():
     lg = torch.ones(d, device=dev); lb = torch.zeros(d, device=dev)
     hn = torch.empty(rows, d, dtype=torch.float16, device=dev)
     x = torch.zeros(rows, d, device=dev)
+    ctr = torch.zeros(1, dtype=torch.int32, device=dev)
     libs = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'micro', 'build', 'libmlp_v*.so')),
                   key=lambda p: (int(re.search(r'_v(\d+)', p).group(1)), p))
     fns = []
@@ -30,13 +31,13 @@ def main():
         f = lib.vittf_block_tail if tail else lib.vittf_mlp_fused
         f.restype = ctypes.c_int
         f.argtypes = ([ctypes.c_void_p] * (8 if tail else 5) + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
-                                                                ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p])
+                                                                ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
         fns.append((re.search(r'_v(\w+)\.so', p).group(1), f))
 
     def run(f):
         pre = (hh.data_ptr(), wpk.data_ptr(), b2.data_ptr(), lg.data_ptr(), lb.data_ptr()) if tail else (hh.data_ptr(), wpk.data_ptr())
         rc = f(*pre, b1.data_ptr(), b2.data_ptr(), x.data_ptr(), rows, d, _lib.DTYPES['fp16'],
-               lg.data_ptr(), lb.data_ptr(), 1e-6, hn.data_ptr(), _lib.stream_ptr())
+               lg.data_ptr(), lb.data_ptr(), 1e-6, hn.data_ptr(), ctr.data_ptr(), _lib.stream_ptr())
         assert rc == 0, rc
     for _, f in fns:
         run(f)

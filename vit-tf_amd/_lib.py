@@ -67,8 +67,9 @@ SIGNATURES = {
     'vittf_gemm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vittf_gemm_residual_ln': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp]),
     'vittf_ln_gemm': (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
-    'vittf_mlp_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp]),
-    'vittf_block_tail': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp]),
+    'vittf_mlp_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
+    'vittf_block_tail_workspace_bytes': (_sz, []),
+    'vittf_block_tail': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vittf_attention_rescale_count': (_i64, [_i32]),
     'vittf_attention_fp8_workspace_bytes': (_sz, [_i32, _i32, _i32]),
@@ -123,7 +124,7 @@ def load():
 
 KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention', 'mlp', 'gemm_qkv', 'gemm_proj', 'gemm_fc1', 'gemm_fc2',
                   'similarity')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def profiler_enable(on=True, classes=None):

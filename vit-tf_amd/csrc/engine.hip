@@ -10,6 +10,7 @@
 //   H    h16  [rows][D]      LayerNorm output / attention output (MFMA operand)
 //   QKV  h16  [rows][3D]     attention input; QKV|O is re-used as the [rows][4D] MLP hidden buffer
 //   O    h16  [rows][D]
+//   (fp8 attention operands, opt-in)   tile counter of the block-tail kernel (4 bytes; one workspace = one stream)
 // Everything is enqueued on the caller's stream; nothing synchronises with the host.
 #include "vittf_common.h"
 
@@ -34,7 +35,7 @@ hipEvent_t prof_event() {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-  size_t x, h, qkv, o, fp8, fp8_bytes, total;
+  size_t x, h, qkv, o, fp8, fp8_bytes, tile_ctr, total;
 };
 
 WsLayout ws_layout(int d, int64_t rows, size_t fp8_bytes = 0) {
@@ -46,6 +47,7 @@ WsLayout ws_layout(int d, int64_t rows, size_t fp8_bytes = 0) {
   l.qkv = off; off += (size_t)rp * 3 * d * 2;   // QKV and O contiguous: together the [rows][4D] hidden buffer
   l.o = off;   off += align256((size_t)rp * d * 2);
   l.fp8 = off; l.fp8_bytes = fp8_bytes; off += align256(fp8_bytes);     // operands of the fp8 attention path (opt-in)
+  l.tile_ctr = off; off += align256(vittf_block_tail_workspace_bytes()); // tile counter of the block-tail / fused-MLP launches
   l.total = off;
   return l;
 }
@@ -175,7 +177,7 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
       rc = vittf_block_tail(O, (const char*)w->tail_packed + (size_t)l * 108 * 12288 * esz, w->proj_b + (size_t)l * d,
                             w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, w->fc1_b + (size_t)l * 4 * d,
                             w->fc2_b + (size_t)l * d, X, rows, d, dt, w->ln1_g + (size_t)(l + 1) * d,
-                            w->ln1_b + (size_t)(l + 1) * d, cfg->ln_eps, H, stream);
+                            w->ln1_b + (size_t)(l + 1) * d, cfg->ln_eps, H, base + lay.tile_ctr, stream);
       if (rc) return rc;
       continue;
     }
@@ -197,7 +199,8 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
       ProfScope ps(VITTF_KERNEL_MLP, stream);
       rc = vittf_mlp_fused(H, (const char*)w->mlp_packed + (size_t)l * 4 * d * d * 2 * esz, w->fc1_b + (size_t)l * 4 * d,
                            w->fc2_b + (size_t)l * d, X, rows, d, dt, res_ln ? w->ln1_g + (size_t)(l + 1) * d : nullptr,
-                           res_ln ? w->ln1_b + (size_t)(l + 1) * d : nullptr, cfg->ln_eps, res_ln ? H : nullptr, stream);
+                           res_ln ? w->ln1_b + (size_t)(l + 1) * d : nullptr, cfg->ln_eps, res_ln ? H : nullptr,
+                           base + lay.tile_ctr, stream);
       if (rc) return rc;
     } else {
       { ProfScope ps(VITTF_KERNEL_GEMM_FC1, stream);

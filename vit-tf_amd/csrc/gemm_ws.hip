@@ -346,11 +346,8 @@ __global__ __launch_bounds__(WTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3))
 template <int DT, bool LNF>
 int launch_ws(const void* a, const void* w, const float* bias, void* out, int64_t rows, int n, int epi, const float* ln_g,
               const float* ln_b, float ln_eps, hipStream_t st) {
-  static const int cus = [] {
-    int dev = 0, v = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-    return v > 0 ? v : 256;
-  }();
+  const int cus = vittf_current_cus();        // per call, of the current device
+  if (cus <= 0) return VITTF_ERR_NO_DEVICE;
   const int n_mt = (int)((rows + WBM - 1) / WBM);
   const int total = n_mt * (n / WNT);
   const int grid = total < cus ? total : cus;

@@ -35,8 +35,6 @@
 
 #include <stdlib.h>
 
-#include <mutex>
-#include <unordered_map>
 
 namespace {
 
@@ -641,32 +639,19 @@ void vittf_note_kernel(int, const char*) {}
 
 static int mlp_launch(bool tail, const void* a, const void* w_packed, const float* bp, const float* g2, const float* e2,
                       const float* b1, const float* b2, float* x, int64_t rows, int32_t dtype, const float* ln_g,
-                      const float* ln_b, float ln_eps, void* h_out, void* stream) {
+                      const float* ln_b, float ln_eps, void* h_out, void* tile_counter, void* stream) {
   const int64_t tiles = (rows + 127) / 128;
   if (tiles > 0x7fffffff) return VITTF_ERR_INVALID_ARG;
   // 16-byte accesses everywhere (LDS-DMA pieces, buffer loads / stores of whole 128-byte runs)
   if ((((uintptr_t)a | (uintptr_t)w_packed | (uintptr_t)x | (uintptr_t)h_out) & 15) != 0) return VITTF_ERR_INVALID_ARG;
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
-  }();
+  if (!tile_counter || ((uintptr_t)tile_counter & 3) != 0) return VITTF_ERR_INVALID_ARG;
+  // one persistent workgroup per CU of the device this call runs on (asked per call: no state is kept between calls)
+  const int cus = vittf_current_cus();
+  if (cus <= 0) return VITTF_ERR_NO_DEVICE;
   const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
   hipStream_t st = (hipStream_t)stream;
-  // the tile counter of this stream (launches on one stream are serialised; two stream lanes run two of these kernels at once)
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, unsigned*> counters;
-  unsigned* ctr = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = counters.find(st);
-    if (it == counters.end()) {
-      if (hipMalloc((void**)&ctr, sizeof(unsigned)) != hipSuccess) return VITTF_ERR_LAUNCH;
-      counters.emplace(st, ctr);
-    } else {
-      ctr = it->second;
-    }
-  }
+  // the tile counter is the caller's memory (launches on one stream are serialised; two stream lanes bring two counters)
+  unsigned* ctr = (unsigned*)tile_counter;
   if (hipMemsetAsync(ctr, 0, sizeof(unsigned), st) != hipSuccess) return VITTF_ERR_LAUNCH;
 #define MLP_LAUNCH(DTV, TAILV)                                                                                       \
   hipLaunchKernelGGL((mlp_kernel<DTV, TAILV>), dim3(grid), dim3(256), 0, st, (const unsigned short*)a,               \
@@ -682,18 +667,23 @@ static int mlp_launch(bool tail, const void* a, const void* w_packed, const floa
 
 extern "C" int vittf_mlp_fused(const void* h, const void* w_packed, const float* b1, const float* b2, float* x, int64_t rows,
                                int32_t d, int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out,
-                               void* stream) {
+                               void* tile_counter, void* stream) {
   if (!h || !w_packed || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
   if (d != D) return VITTF_ERR_INVALID_ARG;          // the register budget is sized for ViT-S
   if ((ln_g || ln_b || h_out) && !(ln_g && ln_b && h_out)) return VITTF_ERR_INVALID_ARG;
-  return mlp_launch(false, h, w_packed, nullptr, nullptr, nullptr, b1, b2, x, rows, dtype, ln_g, ln_b, ln_eps, h_out, stream);
+  return mlp_launch(false, h, w_packed, nullptr, nullptr, nullptr, b1, b2, x, rows, dtype, ln_g, ln_b, ln_eps, h_out, tile_counter,
+                    stream);
 }
+
+extern "C" size_t vittf_block_tail_workspace_bytes(void) { return sizeof(unsigned); }
 
 extern "C" int vittf_block_tail(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g,
                                 const float* ln2_b, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
-                                int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* stream) {
+                                int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* tile_counter,
+                                void* stream) {
   if (!attn_out || !w_packed || !proj_b || !ln2_g || !ln2_b || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
   if (d != D) return VITTF_ERR_INVALID_ARG;
   if ((ln_g || ln_b || h_out) && !(ln_g && ln_b && h_out)) return VITTF_ERR_INVALID_ARG;
-  return mlp_launch(true, attn_out, w_packed, proj_b, ln2_g, ln2_b, b1, b2, x, rows, dtype, ln_g, ln_b, ln_eps, h_out, stream);
+  return mlp_launch(true, attn_out, w_packed, proj_b, ln2_g, ln2_b, b1, b2, x, rows, dtype, ln_g, ln_b, ln_eps, h_out, tile_counter,
+                    stream);
 }

@@ -444,12 +444,8 @@ int vittf_sim_mfma_maps(const unsigned short* feat, int32_t f, int64_t nvox, con
   const unsigned blocks = (unsigned)((nvox + SM_VOX - 1) / SM_VOX);
   // whole-row LDS-DMA needs 16-byte aligned rows; other volumes take the strided loads
   const bool dma = sm_rows_aligned(feat, nvox);
-  // CUs of the CURRENT device (one process per GPU: the rank's device, not device 0), asked once
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
-  }();
+  const int cus = vittf_current_cus();        // of the CURRENT device, per call (the rank's device, not device 0)
+  if (cus <= 0) return VITTF_ERR_NO_DEVICE;
   if (dma && ku == 1 && cl.n == 1 && chunks == 1) {   // the interactive query: one class, one chunk; the kernel prepares the queries itself
     vittf_note_kernel(VITTF_KERNEL_SIMILARITY, "sim_mfma_few_kernel");
     hipLaunchKernelGGL(sim_mfma_few_kernel, dim3(blocks < (unsigned)cus ? blocks : (unsigned)cus), dim3(SM_THREADS), 0, st, feat, nvox,

@@ -163,6 +163,14 @@ struct ProfScope {
 // which kernel a dispatcher launched for a profiler class (bench.py asks instead of re-deriving the dispatch rules)
 void vittf_note_kernel(int cls, const char* name);
 
+// Compute units of the device the CALLING thread has current -- asked on every call, never latched: a process that drives
+// two GPUs (HipViT takes a device) must size each persistent grid for the device it launches on.  <= 0: no device.
+static inline int vittf_current_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess ? n : 0;
+}
+
 static inline int vittf_check_launch() {
   return hipGetLastError() == hipSuccess ? VITTF_OK : VITTF_ERR_LAUNCH;
 }
