@@ -138,7 +138,7 @@ def compute_qkv(vol, model, patch_size, im_sizes, pool_fn=_noop, batch_size=1, s
     if patch_size != model.patch_size:
         raise ValueError(f'patch_size {patch_size} != model patch size {model.patch_size}')
     dvol = vt.DeviceVolume(vol, model.device)
-    eb = int(batch_size) if int(batch_size) > 1 else None      # 1 = the reference's default: the engine sizes its own batch
+    eb = vt.extract.AtLeast(batch_size) if int(batch_size) > 1 else None      # a lower bound: the engine sizes its own calls
     out = {}
     for key in return_keys:
         part = vt.extract.PARTS[key]
@@ -279,7 +279,7 @@ def main(argv=None):
     model = dino_model_fn(dino_model)
     torch.cuda.synchronize()
     t0 = time.time()
-    eb = args.batch_size if args.batch_size > 1 else None        # (results do not depend on it; extract.engine_batch_for)
+    eb = vt.extract.AtLeast(args.batch_size) if args.batch_size > 1 else None   # a lower bound (extract.engine_batch_for)
     feats = vt.feature_volume(vol, model, args.feature_output_size, args.slice_along, eb)
     if args.slice_along == 'all':
         qkv = defaultdict(float)           # the reference saves a defaultdict in 'all' mode (:328)

@@ -218,6 +218,9 @@ def test_engine_batch_follows_a_workspace_budget(monkeypatch):
     assert engine_batch_for(16385, 768) == 64
     assert engine_batch_for(65, 384) == 256 and engine_batch_for(10 ** 9, 384) == 1
     assert engine_batch_for(4097, 384, 32) == 32
+    from vit_tf_amd.extract import AtLeast             # the reference's --batch-size: a lower bound, never a smaller launch
+    assert engine_batch_for(4097, 384, AtLeast(4)) == 256 and engine_batch_for(4097, 384, AtLeast(300)) == 300
+    assert engine_batch_for(16385, 384, AtLeast(2)) == 64
     monkeypatch.setenv('VITTF_ENGINE_BATCH', '8')
     assert engine_batch_for(4097, 384, 32) == 8
 

@@ -17,6 +17,9 @@ step() {  # step <name> <timeout-seconds> <cmd...>
 : > $OUT/summary.log
 for s in "$@"; do
   case $s in
+    allgpu)   # what the driver runs at round end: the whole -m gpu suite as ONE process (900 s limit there)
+              step test_all 900 python -m pytest tests -x -q -m gpu -s --durations=25 -p no:cacheprovider ;;
+    fos128)   VITTF_BENCH_OVERLAP=0 step bench512_fos128 900 python bench.py --fos 128 --steps 2 --warmup 1 --cpu-slices 0 ;;
     kernels)  step test_kernels 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider ;;
     pipeline) step test_pipeline 900 python -m pytest tests/test_gpu_pipeline.py -q -m gpu -s -p no:cacheprovider ;;
     smoke)    step smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;

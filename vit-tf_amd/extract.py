@@ -25,18 +25,29 @@ AXIS_DIMS = {'z': (2, (0, 1)), 'y': (1, (0, 2)), 'x': (0, (1, 2))}
 DEFAULT_ENGINE_BATCH = 256
 
 
+class AtLeast(int):
+    """An engine-batch request that is a LOWER bound: what the reference's `--batch-size` / `compute_qkv(batch_size=...)`
+    become here.  The reference's mini-batch bounds its GPU memory; this engine sizes its own calls (a 4-slice launch is
+    ~128 row tiles for 256 CUs and runs several times slower for the same bits), so the flag may raise the engine's
+    batch but never lowers it.  A plain int (bench.py --engine-batch, the tests) is taken literally."""
+
+
 def engine_batch_for(tokens, embed_dim, requested=None):
     """Slices per engine call.  The default keeps the ROW count of a call at what 256 slices of N = 4097 are (1.05 M rows:
     5.6 GB of workspace per stream lane at D = 384, 11 GB at D = 768; the widest buffer, rows x 4 D 16-bit values, stays
     below 2^32 elements), whatever the token count: 256 * 4097 / tokens, clamped to 1 .. 256 -- the fos-128 preset
-    (N = 16385) then runs 64 slices per call.  `requested` (infer.py --batch-size > 1, bench.py --engine-batch) or
-    VITTF_ENGINE_BATCH lower or raise it; results never depend on it."""
+    (N = 16385) then runs 64 slices per call.  `requested`: a plain int (bench.py --engine-batch, tests) is taken
+    literally, an `AtLeast` (infer.py --batch-size, compute_qkv's batch_size) only raises the default; VITTF_ENGINE_BATCH
+    overrides both; results never depend on any of them."""
     env = __import__('os').environ.get('VITTF_ENGINE_BATCH')
     if env:
         return max(1, int(env))
+    default = max(1, min(DEFAULT_ENGINE_BATCH, DEFAULT_ENGINE_BATCH * 4097 // int(tokens)))
+    if isinstance(requested, AtLeast):
+        return max(int(requested), default)
     if requested:
         return max(1, int(requested))
-    return max(1, min(DEFAULT_ENGINE_BATCH, DEFAULT_ENGINE_BATCH * 4097 // int(tokens)))
+    return default
 
 
 # Batches of slices are independent, so consecutive batches can go round-robin onto several HIP streams (each with
@@ -237,6 +248,8 @@ def _all_gather_slabs(gathered, slab, group, defer=False):
         # in place: this rank's slab already sits at flat[rank], which is exactly where an all-gather writes the rank's own
         # contribution (send buffer = receive buffer + rank * count, RCCL's in-place form): no staging copy
         mine = flat[torch.distributed.get_rank(group)]
+        if slab.data_ptr() != mine.data_ptr():
+            raise RuntimeError('in-place all-gather: this rank\'s slab is not its slot of the receive buffer')
         if defer:
             return torch.distributed.all_gather_into_tensor(flat.view(-1), mine, group=group, async_op=True), mine
         torch.distributed.all_gather_into_tensor(flat.view(-1), mine, group=group)
