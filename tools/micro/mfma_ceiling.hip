@@ -109,6 +109,37 @@ __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ sr
         asm volatile("v_exp_f32 %0, %4\n\tv_exp_f32 %1, %5\n\tv_cvt_pk_f16_f32 %2, %6, %7\n\tv_dot2c_f32_f16 %3, %8, %9"
                      : "=&v"(ea0), "=&v"(ea1), "=&v"(pk), "+v"(s0) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1), "v"(pkprev), "v"(0x3c003c00u));
         pkprev = pk;
+      } else if constexpr (FILL == 11 || FILL == 12) {
+       if (FILL == 11 || (m & 1)) {
+        // the exponentials of a gap's TWO scores WITHOUT the transcendental unit -- Cody-Waite on packed
+        // fp16: t = cvt_pk(s0, s1); clamp (far keys must flush to zero, not wrap the exponent field); u = t + 1536 (ulp 1:
+        // the integer part lands in the low mantissa bits); r = u - 1536; g = t - r in [-1/2, 1/2]; degree-3 polynomial for
+        // 2^g (3 v_pk_fma_f16); exponent insert by integer arithmetic (v_pk_mad_u16: u * 1024 + bits, mod 2^16); max(., 0)
+        // (an underflowed exponent field wraps into the sign bit: negative / NaN -> 0); row sum of the packed pair by
+        // v_dot2_f32_f16.  11 VALU for two values where the v_exp mix has 5 (2 v_exp, 2 v_add, 1 v_cvt_pk).
+        // FILL == 12: every second gap this way, the others with v_exp ("half of a tile's exponentials off the unit").
+        unsigned t_, u_, r_, g_, p_;
+        asm volatile("v_cvt_pk_f16_f32 %0, %6, %7\n\tv_pk_max_f16 %0, %0, %8\n\tv_pk_add_f16 %1, %0, %9\n\t"
+                     "v_pk_add_f16 %2, %1, %9 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f16 %3, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                     "v_pk_fma_f16 %4, %3, %10, %11\n\tv_pk_fma_f16 %4, %4, %3, %12\n\tv_pk_fma_f16 %4, %4, %3, %13\n\t"
+                     "v_pk_mad_u16 %4, %1, %14, %4\n\tv_pk_max_f16 %4, %4, %15\n\tv_dot2_f32_f16 %5, %4, %16, %5"
+                     : "=&v"(t_), "=&v"(u_), "=&v"(r_), "=&v"(g_), "=&v"(p_), "+v"(s0)
+                     : "v"(x[0]), "v"(x[1]), "v"(0xcb00cb00u), "v"(0x66006600u), "v"(0x2b1b2b1bu), "v"(0x33b033b0u), "v"(0x398c398cu),
+                       "v"(0x3c003c00u), "v"(0x04000400u), "v"(0u), "v"(0x3c003c00u));
+        pk = p_;
+       } else        // (the even gaps of FILL == 12: the v_exp mix)
+        asm volatile("v_exp_f32 %0, %5\n\tv_exp_f32 %1, %6\n\tv_add_f32 %2, %2, %7\n\tv_add_f32 %3, %3, %8\n\tv_cvt_pk_f16_f32 %4, %7, %8"
+                     : "=&v"(ea0), "=&v"(ea1), "+v"(s0), "+v"(s1), "=&v"(pk) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1));
+      } else if constexpr (FILL == 13) { // the packed-fp16 route with its row sums left out (its floor): 10 packed VALU per two values
+        unsigned t_, u_, r_, g_, p_;
+        asm volatile("v_cvt_pk_f16_f32 %0, %5, %6\n\tv_pk_max_f16 %0, %0, %7\n\tv_pk_add_f16 %1, %0, %8\n\t"
+                     "v_pk_add_f16 %2, %1, %8 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f16 %3, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                     "v_pk_fma_f16 %4, %3, %9, %10\n\tv_pk_fma_f16 %4, %4, %3, %11\n\tv_pk_fma_f16 %4, %4, %3, %12\n\t"
+                     "v_pk_mad_u16 %4, %1, %13, %4\n\tv_pk_max_f16 %4, %4, %14"
+                     : "=&v"(t_), "=&v"(u_), "=&v"(r_), "=&v"(g_), "=&v"(p_)
+                     : "v"(x[0]), "v"(x[1]), "v"(0xcb00cb00u), "v"(0x66006600u), "v"(0x2b1b2b1bu), "v"(0x33b033b0u), "v"(0x398c398cu),
+                       "v"(0x3c003c00u), "v"(0x04000400u), "v"(0u));
+        pk = p_;
       } else if constexpr (FILL == 5) { // three plain VALU (the mix without its exps)
         asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_cvt_pk_f16_f32 %2, %3, %4"
                      : "+v"(s0), "+v"(s1), "=&v"(pk) : "v"(eb0), "v"(eb1));
@@ -185,6 +216,10 @@ int main() {
     run<4, 8>("MFMA + 2 v_exp + 1 v_cvt_pk + 1/2 mfma_4x4x4 (row sums)", w, src, out, st);
     run<4, 9>("MFMA + 2 v_exp + 1 v_cvt_pk + 1 v_dot2_f32_f16", w, src, out, st);
     run<4, 10>("MFMA + 2 v_exp + 1 v_cvt_pk + 1 v_dot2c_f32_f16", w, src, out, st);
+    run<4, 11>("MFMA + packed-fp16 polynomial exp2 x 2 (11 VALU, no v_exp)", w, src, out, st);
+    run<4, 12>("MFMA + v_exp mix / packed polynomial in alternate gaps", w, src, out, st);
+    run<4, 13>("MFMA + packed polynomial exp2 x 2 without row sums (10)", w, src, out, st);
+    run<4, 11, 0>("no MFMA: packed-fp16 polynomial exp2 x 2 (11 VALU)", w, src, out, st);
     run<4, 9, 0>("no MFMA: 2 v_exp + 1 v_cvt_pk + 1 v_dot2_f32_f16", w, src, out, st);
     run<4, 10, 0>("no MFMA: 2 v_exp + 1 v_cvt_pk + 1 v_dot2c_f32_f16", w, src, out, st);
     run<4, 6>("MFMA + 1 v_cvt_pk + 2 v_exp_f16", w, src, out, st);

