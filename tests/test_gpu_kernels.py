@@ -53,7 +53,8 @@ def _gemm_inputs(rows, n, k, dt, seed):
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('rows,n,k', [(1, 128, 64), (100, 128, 128), (128, 384, 384), (300, 1152, 384),
-                                      (257, 384, 1536), (8194, 1536, 384), (19205, 1152, 384)])
+                                      (257, 384, 1536), (8194, 1536, 384), (19205, 1152, 384),
+                                      (1, 256, 768), (300, 2304, 768), (4097, 3072, 768), (513, 768, 3072), (8194, 256, 832), (700, 128, 768)])   # K >= 768, N % 256 == 0: gemm_pp.hip
 def test_gemm_bias_and_gelu(gpu, dt, rows, n, k):
     lib = _lib.load()
     a, w, bias, ref = _gemm_inputs(rows, n, k, dt, rows + n + k)

@@ -40,7 +40,8 @@ def main():
     lib = _lib.load()
     dev = torch.device('cuda', 0)
     dt = os.environ.get('DT', 'fp16')
-    batch, tokens, heads, d = int(os.environ.get('BATCH', '32')), int(os.environ.get('TOKENS', '4097')), 6, 384
+    d = int(os.environ.get('D', '384'))                    # D=768: the ViT-B/8 shapes (BASELINE configs[3])
+    batch, tokens, heads = int(os.environ.get('BATCH', '32')), int(os.environ.get('TOKENS', '4097')), d // 64
     rows = batch * tokens
     g = torch.Generator(device='cpu').manual_seed(0)
     if 'attn' in what:

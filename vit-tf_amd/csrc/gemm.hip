@@ -27,20 +27,6 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KB
 
-__device__ __forceinline__ float gelu_erf(float x) {
-  // exact-erf GELU 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = 1.0f - p * __expf(-z * z);
-  const float erfv = x < 0.f ? -e : e;
-  return 0.5f * x * (1.0f + erfv);
-}
-
 // issue the LDS-DMA of one [128][64] operand tile: 1024 16-byte chunks, 4 per thread (asm pieces, see lds_dma16:
 // with the builtin, hipcc drains vmcnt(0) before the fragment reads of the tile being multiplied, which is what
 // made the two-stage pipeline slower than the single stage)
@@ -193,7 +179,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_kernel(const un
           float v2 = acc[ni][mi][4 * g + 2] + bv.z;
           float v3 = acc[ni][mi][4 * g + 3] + bv.w;
           if constexpr (EPI == VITTF_EPI_BIAS_GELU) {
-            v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+            v0 = gelu_poly(v0); v1 = gelu_poly(v1); v2 = gelu_poly(v2); v3 = gelu_poly(v3);
           }
           if constexpr (EPI == VITTF_EPI_BIAS_QKV) {
             // the q third carries the softmax scale and the exp -> exp2 base change: one rounding, like plain q
@@ -279,6 +265,15 @@ int vittf_gemm_ws(const void* a, const void* w, const float* bias, void* out, in
 int vittf_gemm_rows(const void* a, const void* w, const float* bias, float* x, int64_t rows, int32_t n, int32_t k,
                     int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h, hipStream_t st);   // gemm_rows.hip
 
+int vittf_gemm_pp(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
+                  int32_t epilogue, int32_t tokens, int32_t dtype, hipStream_t st);   // gemm_pp.hip; 1 = not covered
+
+// VITTF_GEMM_PP (default 1): K >= 768 with N % 256 == 0 (the ViT-B linears) on the 8-wave ping-pong kernel of gemm_pp.hip;
+// 0: gemm.hip's 128 x 128 tiles.  VITTF_PP_RESIDUAL (default 0): 1 = also the residual linears with 768 output columns
+// (proj, fc2); the LayerNorm behind them then runs as its own launch instead of in the whole-row kernel's epilogue.
+static bool use_pp() { static const bool v = [] { const char* e = getenv("VITTF_GEMM_PP"); return !e || atoi(e) != 0; }(); return v; }
+static bool use_pp_residual() { static const bool v = [] { const char* e = getenv("VITTF_PP_RESIDUAL"); return e && atoi(e) != 0; }(); return v; }
+
 extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n,
                           int32_t k, int32_t epilogue, int32_t tokens, int32_t dtype, void* stream) {
   if (!a || !w || !bias || !out || rows <= 0 || n <= 0 || k <= 0) return VITTF_ERR_INVALID_ARG;
@@ -295,8 +290,13 @@ extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void*
   // residual epilogue with 384 / 768 output columns (ViT-S / ViT-B proj and fc2): whole-row kernel (VITTF_GEMM_ROWS=0:
   // tiled kernel only)
   static const bool use_rows = [] { const char* e = getenv("VITTF_GEMM_ROWS"); return !e || atoi(e) != 0; }();
-  if (use_rows && epilogue == VITTF_EPI_BIAS_RESIDUAL && (n == 384 || n == 768)) {
+  const bool pp_first = use_pp() && use_pp_residual() && n == 768 && k >= 768;
+  if (use_rows && !pp_first && epilogue == VITTF_EPI_BIAS_RESIDUAL && (n == 384 || n == 768)) {
     const int rc = vittf_gemm_rows(a, w, bias, (float*)out, rows, n, k, dtype, nullptr, nullptr, 0.f, nullptr, st);
+    if (rc != 1) return rc;
+  }
+  if (use_pp()) {
+    const int rc = vittf_gemm_pp(a, w, bias, out, rows, n, k, epilogue, tokens, dtype, st);
     if (rc != 1) return rc;
   }
   if (dtype == VITTF_BF16) return launch_gemm<VITTF_BF16>(a, w, bias, out, rows, n, k, epilogue, tokens, st);
@@ -315,7 +315,7 @@ extern "C" int vittf_gemm_residual_ln(const void* a, const void* w, const float*
   if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   static const bool use_rows = [] { const char* e = getenv("VITTF_GEMM_ROWS"); return !e || atoi(e) != 0; }();
-  if (use_rows && (n == 384 || n == 768)) {
+  if (use_rows && (n == 384 || n == 768) && !(use_pp() && use_pp_residual() && n == 768 && k >= 768)) {
     const int rc = vittf_gemm_rows(a, w, bias, x, rows, n, k, dtype, ln_g, ln_b, ln_eps, h, st);
     if (rc != 1) return rc;
   }
