@@ -268,11 +268,13 @@ int vittf_gemm_rows(const void* a, const void* w, const float* bias, float* x, i
 int vittf_gemm_pp(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
                   int32_t epilogue, int32_t tokens, int32_t dtype, hipStream_t st);   // gemm_pp.hip; 1 = not covered
 
-// VITTF_GEMM_PP (default 1): K >= 768 with N % 256 == 0 (the ViT-B linears) on the 8-wave ping-pong kernel of gemm_pp.hip;
-// 0: gemm.hip's 128 x 128 tiles.  VITTF_PP_RESIDUAL (default 0): 1 = also the residual linears with 768 output columns
-// (proj, fc2); the LayerNorm behind them then runs as its own launch instead of in the whole-row kernel's epilogue.
+// VITTF_GEMM_PP (default 1): K >= 768 with N % 256 == 0 (the ViT-B linears) on the persistent 256 x 256 kernel of
+// gemm_pp.hip; 0: gemm.hip's 128 x 128 tiles.  VITTF_PP_RESIDUAL: the residual linears with 768 output columns whose K is at
+// least this (default 3072: fc2 -- the LayerNorm behind it then runs as its own launch instead of in the whole-row kernel's
+// epilogue: 1.56 against 1.87 ms per 64 slices; proj, K = 768, stays on the whole-row kernel; 768: both; 0: neither).
 static bool use_pp() { static const bool v = [] { const char* e = getenv("VITTF_GEMM_PP"); return !e || atoi(e) != 0; }(); return v; }
-static bool use_pp_residual() { static const bool v = [] { const char* e = getenv("VITTF_PP_RESIDUAL"); return e && atoi(e) != 0; }(); return v; }
+static int pp_residual_min_k() { static const int v = [] { const char* e = getenv("VITTF_PP_RESIDUAL"); return e ? atoi(e) : 3072; }(); return v; }
+static bool use_pp_residual(int k) { const int m = pp_residual_min_k(); return m > 0 && k >= m; }
 
 extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n,
                           int32_t k, int32_t epilogue, int32_t tokens, int32_t dtype, void* stream) {
@@ -290,7 +292,7 @@ extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void*
   // residual epilogue with 384 / 768 output columns (ViT-S / ViT-B proj and fc2): whole-row kernel (VITTF_GEMM_ROWS=0:
   // tiled kernel only)
   static const bool use_rows = [] { const char* e = getenv("VITTF_GEMM_ROWS"); return !e || atoi(e) != 0; }();
-  const bool pp_first = use_pp() && use_pp_residual() && n == 768 && k >= 768;
+  const bool pp_first = use_pp() && use_pp_residual(k) && n == 768 && k >= 768;
   if (use_rows && !pp_first && epilogue == VITTF_EPI_BIAS_RESIDUAL && (n == 384 || n == 768)) {
     const int rc = vittf_gemm_rows(a, w, bias, (float*)out, rows, n, k, dtype, nullptr, nullptr, 0.f, nullptr, st);
     if (rc != 1) return rc;
@@ -315,7 +317,7 @@ extern "C" int vittf_gemm_residual_ln(const void* a, const void* w, const float*
   if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   static const bool use_rows = [] { const char* e = getenv("VITTF_GEMM_ROWS"); return !e || atoi(e) != 0; }();
-  if (use_rows && (n == 384 || n == 768) && !(use_pp() && use_pp_residual() && n == 768 && k >= 768)) {
+  if (use_rows && (n == 384 || n == 768) && !(use_pp() && use_pp_residual(k) && n == 768 && k >= 768)) {
     const int rc = vittf_gemm_rows(a, w, bias, x, rows, n, k, dtype, ln_g, ln_b, ln_eps, h, st);
     if (rc != 1) return rc;
   }

@@ -1,26 +1,33 @@
 // Ping-pong MFMA GEMM for the long-K linears of ViT-B (D = 768: attn.qkv, attn.proj, mlp.fc1 + GELU, mlp.fc2):
-//     out = epilogue(A[rows][K] . W[N][K]^T + bias[N]),   K % 32 == 0, K >= 768, N % 256 == 0
+//     out = epilogue(A[rows][K] . W[N][K]^T + bias[N]),   K % 64 == 0, K >= 768, N % 256 == 0
 //
 // Round 4 (BASELINE configs[3]).  gemm.hip's 128 x 128 x 64 tiles (one stage, four workgroups per CU) run these shapes at
-// 740-870 TFLOP/s; a first pipelined 256 x 128 kernel with two workgroups per CU (3-deep ring, one barrier per 32-wide K step,
-// 6 LDS-DMA pieces per wave and 16 MFMAs) was SLOWER (800): every wave of it alternates between issuing memory work and
-// issuing MFMAs, and an LDS-DMA piece costs 60-180 issue cycles.  This kernel separates the two in time and pairs them in
-// space (MI355X_MICROARCH.md "Two waves per SIMD"; the 8-wave ping-pong schedule):
-//   * workgroup = 8 waves = 2 groups of 4 on a 256 x 256 output tile; wave (g, c) owns rows 128 g .. + 127 and columns
-//     64 c .. + 63 = 4 x 2 accumulator tiles (128 VGPRs), computed transposed like the other GEMMs (weights = MFMA A operand,
-//     activations = B operand: a lane owns one activation row and 4 consecutive columns per register quad).  Waves w and w + 4
-//     share a SIMD: the two groups are SIMD partners.
+// 740-870 TFLOP/s.  Two earlier forms of this file are in the history with their numbers: a pipelined
+// 256 x 128 kernel with two workgroups per CU (800: every wave alternates between memory issue and MFMA issue, and an LDS-DMA
+// piece costs 100+ issue cycles) and a first ping-pong kernel whose load segment carried the 12 fragment reads as well as
+// the 4 DMA pieces (800-870: stamps showed 700 cycles of load segment beside 560 of MFMA segment, and its epilogue -- 128 KB
+// of output per tile at the ~10 bytes per cycle a single workgroup's stores reach -- cost 24-32 % of the launch).  This form:
+//   * workgroup = 8 waves = 2 groups of 4 on a 256 x 256 output tile, persistent (one per CU); wave (g, c) owns rows
+//     128 g .. + 127 and columns 64 c .. + 63 = 4 x 2 accumulator tiles (128 VGPRs), computed transposed like the other GEMMs
+//     (weights = MFMA A operand, activations = B operand: a lane owns one activation row and 4 consecutive columns per
+//     register quad).  Waves w and w + 4 share a SIMD: the two groups are SIMD partners.
 //   * a K step of 32 = a stage: [256][32] activation image + [256][32] weight image = 32 KB in the "double-row" layout of
-//     gemm_rows.hip (conflict-free ds_read_b128); 4-deep ring = 128 KB, one workgroup per CU.
-//   * per stage a wave runs a LOAD segment -- its 12 fragment reads of stage t, its 4 LDS-DMA pieces of stage t + 3, the counted
-//     wait for its pieces of stage t + 1 -- and an MFMA segment (16 MFMAs, s_setprio 1), each closed by a workgroup barrier;
-//     group 1 runs one barrier behind group 0, so while one group's waves issue MFMAs their SIMD partners issue memory work:
-//     the matrix pipe of a SIMD always has a wave in its MFMA segment.  0.75 LDS reads and 0.25 DMA pieces per MFMA.
-//   * hazards by construction: stage t is read in slots 2 t (group 0) and 2 t + 1 (group 1); every wave has waited for its
-//     pieces of stage t in its load segment of stage t - 1 (slots 2 t - 2, 2 t - 1), in front of a barrier the readers pass;
-//     the pieces of stage t + 3 overwrite the slot of stage t - 1, last read in slot 2 t - 1 with lgkmcnt(0) in front of that
-//     slot's closing barrier, and are issued in slots 2 t and 2 t + 1.
-//   * epilogue through LDS (the ring is dead) in row halves / quarters so that every global access is a whole row segment.
+//     gemm_rows.hip (conflict-free ds_read_b128); 4-deep ring = 128 KB.  The stages of a workgroup's tiles form ONE stream:
+//     the ring never drains between tiles.
+//   * per stage p a wave runs a LOAD segment -- its 4 LDS-DMA pieces of stage p + 3 -- and an MFMA segment -- 16 MFMAs on the
+//     fragments of stage p with the 12 fragment reads of stage p + 1 between them (two fragment sets in registers; a
+//     ds_read_b128 in an MFMA gap is nearly free), then the counted wait for its pieces of stage p + 2 --, each closed by a
+//     workgroup barrier; group 1 runs one barrier behind group 0, so while one group's waves issue MFMAs their SIMD partners
+//     issue memory work.  0.75 LDS reads and 0.25 DMA pieces per MFMA.
+//   * hazards by construction: stage p + 1 is read in the MFMA segments of stage p (slots 2 p + 1 and 2 p + 2); every wave
+//     has waited for its pieces of stage p + 1 at the end of its MFMA segment of stage p - 1 (slots 2 p - 1, 2 p), in front
+//     of a barrier every reader passes first; the pieces of stage p + 3 overwrite the slot of stage p - 1, whose last read
+//     (slot 2 p - 2, lgkmcnt(0) in front of its closing barrier) precedes their issue (slots 2 p, 2 p + 1).
+//   * epilogue: the groups are brought level (one barrier), the tile leaves in eight parts of 32 rows through a 32 KB fp32
+//     staging area BEHIND the ring: four waves stage their accumulators, all eight apply bias / GELU / q scale (or the fp32
+//     residual read-modify-write) and issue whole-row-segment buffer stores that stay in flight under the next tile's K loop
+//     -- whose first three stages are already in the ring -- then group 1 drops one barrier behind again.  The counted waits
+//     know how many stores a tile leaves behind.
 //   * a partial last row tile reads zeros for its missing rows (descriptor bounds) and drops their outputs: a row's bits do
 //     not depend on where it sits in a launch.
 #include "vittf_common.h"
@@ -33,9 +40,10 @@ constexpr int PBM = 256, PBN = 256, PBK = 32;
 constexpr int PIMG = 256 * PBK * 2;              // one operand image: 16 KB
 constexpr int PSTAGE = 2 * PIMG;                 // 32 KB
 constexpr int PSTAGES = 4;
-constexpr int PLDS = PSTAGES * PSTAGE;           // 128 KB
-constexpr int PCS = 512 + 16;                    // staging row stride: 128 rows x 528 B = 67,584 B
-static_assert(128 * PCS <= PLDS, "the C tile re-uses the ring");
+constexpr int PRING = PSTAGES * PSTAGE;          // 128 KB
+constexpr int PSTG = 32768;                      // staging behind the ring: 32 rows x 256 fp32 columns
+constexpr int PLDS = PRING + PSTG;               // 160 KB
+static_assert(PLDS <= 160 * 1024, "LDS");
 
 #define PP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -44,45 +52,32 @@ static_assert(128 * PCS <= PLDS, "the C tile re-uses the ring");
 #define PP_VARIANT 0
 #endif
 constexpr bool PV_NO_DMA = PP_VARIANT & 1;       // no LDS-DMA inside the K loop (wrong results)
-constexpr bool PV_KEEP_M0 = PP_VARIANT & 2;      // LDS-DMA pieces that leave M0 pointing at their destination (no save / restore)
-constexpr bool PV_NO_READS = PP_VARIANT & 4;     // fragments read once, before the K loop (wrong results)
-constexpr bool PV_SPLIT_DMA = PP_VARIANT & 8;    // two of the four pieces of a stage issued at the head of the MFMA segment
-constexpr bool PV_NO_PRIO = PP_VARIANT & 16;     // no s_setprio around the MFMA segment
-constexpr bool PV_NO_EPI = PP_VARIANT & 32;      // no epilogue (wrong results)
-constexpr bool PV_STAMPS = PP_VARIANT & 64;      // s_memtime at the segment boundaries, summed over a tile's K loop
-#if PP_VARIANT & 64
-__device__ unsigned long long g_pp_stamps[8 /*workgroups*/][8 /*waves*/][6];
-#define PP_T(k) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tacc[k] += t_ - tprev; tprev = t_; }
-#else
-#define PP_T(k)
-#endif
+constexpr bool PV_NO_READS = PP_VARIANT & 4;     // no fragment reads inside the K loop (wrong results)
 
-__device__ __forceinline__ void pp_dma16_keep(i32x4_t rsrc, unsigned lds_addr, int voff, int soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void pp_dma16(i32x4_t rsrc, unsigned lds_addr, int voff, int soff) {
-  if constexpr (PV_KEEP_M0) pp_dma16_keep(rsrc, lds_addr, voff, soff);
-  else lds_dma16(rsrc, lds_addr, voff, soff);
-}
+constexpr bool PV_NO_EPI = PP_VARIANT & 32;      // no epilogue (wrong results)
+constexpr bool PV_NO_PIN = PP_VARIANT & 128;     // no scheduling fences inside the MFMA segment (the compiler places the reads)
 
 // byte offset of 16-byte k-chunk kc (0..3) of row r inside a [R][32] operand image (two rows per 128-byte tile_off row)
 __device__ __forceinline__ int p_img_off(int r, int kc) { return tile_off(r >> 1, ((r & 1) << 2) | kc); }
 
+typedef __attribute__((ext_vector_type(4))) unsigned pu32x4_t;
+
+struct Frags { s16x8_t a[4][2], w[2][2]; };      // [32-row block][k16 step]
+
 template <int DT, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W,
                                                          const float* __restrict__ bias, void* __restrict__ out, int64_t rows,
-                                                         int n, int k, int tokens, int n_tiles, int total_tiles) {
+                                                         int n, int k, int tokens, int n_tiles, int total_tiles,
+                                                         unsigned out_bytes) {
   __shared__ __attribute__((aligned(16))) char smem[PLDS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
   const int grp = wave >> 2, wc = wave & 3;      // waves w and w + 4 share a SIMD: the two groups are SIMD partners
-
-  const int tile = xcd_remap(blockIdx.x, total_tiles);
-  const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
-  const int64_t m0 = (int64_t)mt * PBM;
-  const int n0 = nt * PBN;
+  const int G = gridDim.x;
+  const int nk = k / PBK;                        // even, >= 24
+  // buffer stores a thread leaves in flight per tile: 8 parts x 4 (fp32 read-modify-write) or x 2 (16 bytes of 16-bit values)
+  constexpr int SPT = EPI == VITTF_EPI_BIAS_RESIDUAL ? 32 : 16;
 
   // ---- LDS-DMA: chunk q = i * 512 + tid of an image <- (row, k chunk) by the inverse of p_img_off; 2 + 2 pieces per wave ----
   int voff[2];
@@ -92,228 +87,239 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
     tile_pos(i * 512 + tid, dr, c);
     voff[i] = (2 * dr + (c >> 2)) * k * 2 + (c & 3) * 16;
   }
-  const int rows_here = (int)(rows - m0 < PBM ? rows - m0 : PBM);
-  const i32x4_t rsrc_a = lds_dma_rsrc(A + m0 * k, (unsigned)((int64_t)rows_here * k * 2));
-  const i32x4_t rsrc_w = lds_dma_rsrc(W + (int64_t)n0 * k, (unsigned)(PBN * k * 2));
   const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(smem);
   const unsigned dma_wave = ring_lds + wave * 1024;
-#define PP_STAGE_A(T, BUF)                                                  \
-  {                                                                         \
-    const unsigned dst_ = dma_wave + (BUF) * PSTAGE;                        \
-    const int so_ = (T) * (PBK * 2);                                        \
-    pp_dma16(rsrc_a, dst_, voff[0], so_);                                   \
-    pp_dma16(rsrc_a, dst_ + 8192, voff[1], so_);                            \
-  }
-#define PP_STAGE_W(T, BUF)                                                  \
-  {                                                                         \
-    const unsigned dst_ = dma_wave + (BUF) * PSTAGE;                        \
-    const int so_ = (T) * (PBK * 2);                                        \
-    pp_dma16(rsrc_w, dst_ + PIMG, voff[0], so_);                            \
-    pp_dma16(rsrc_w, dst_ + PIMG + 8192, voff[1], so_);                     \
-  }
-#define PP_STAGE(T, BUF) { PP_STAGE_A(T, BUF) PP_STAGE_W(T, BUF) }
 
-  // ---- fragment addresses inside a stage ----
-  int aoff[4][2], woff[2][2];                    // [32-row block][k16 step]
+  // ---- the DMA stream: (tile, K step) of the next stage to request, its descriptors, its ring slot ----
+  int d_vb = blockIdx.x, d_k = 0, d_slot = 0;
+  bool d_live = true;
+  i32x4_t d_ra, d_rw;
+  auto tile_origin = [&](int vb, int64_t& m0, int& n0) {
+    const int tile = xcd_remap(vb, total_tiles);
+    const int mt = tile / n_tiles;
+    m0 = (int64_t)mt * PBM;
+    n0 = (tile - mt * n_tiles) * PBN;
+  };
+  auto d_open = [&](int vb) {
+    int64_t m0; int n0;
+    tile_origin(vb, m0, n0);
+    const int rows_here = (int)(rows - m0 < PBM ? rows - m0 : PBM);
+    d_ra = lds_dma_rsrc(A + m0 * k, (unsigned)((int64_t)rows_here * k * 2));
+    d_rw = lds_dma_rsrc(W + (int64_t)n0 * k, (unsigned)(PBN * k * 2));
+  };
+  d_open(d_vb);
+  // one piece (0..3) of the next stage of the stream; piece 3 advances the stream.  Returns false when the stream is over.
+  auto dma_piece = [&](int i) -> bool {
+    if (!d_live) return false;
+    const unsigned dst = dma_wave + d_slot * PSTAGE;
+    const int so = d_k * (PBK * 2);
+    if (i == 0) lds_dma16(d_ra, dst, voff[0], so);
+    else if (i == 1) lds_dma16(d_ra, dst + 8192, voff[1], so);
+    else if (i == 2) lds_dma16(d_rw, dst + PIMG, voff[0], so);
+    else {
+      lds_dma16(d_rw, dst + PIMG + 8192, voff[1], so);
+      d_slot = (d_slot + 1) & 3;
+      if (++d_k == nk) {
+        d_k = 0;
+        d_vb += G;
+        if (d_vb < total_tiles) d_open(d_vb); else d_live = false;
+      }
+    }
+    return true;
+  };
+  auto dma_next = [&]() { dma_piece(0); dma_piece(1); dma_piece(2); dma_piece(3); };
+
+  // ---- fragment addresses inside a stage: block mi of 32 rows = + 2048 mi with byte bit 7 flipped for odd mi, k16 step 1 =
+  //      byte bit 5 flipped (the swizzle of tile_off): two base registers, everything else is recomputed per stage (as loop
+  //      invariants the twelve addresses are spilled) ----
+  const int a_base0 = p_img_off(grp * 128 + l31, h), w_base0 = PIMG + p_img_off(wc * 64 + l31, h);
+  int r_slot = 0;                                // ring slot of the stage whose fragments are read next
+  typedef __attribute__((address_space(3))) const s16x8_t* lds_frag_ptr;
+  const unsigned lbase = (unsigned)(size_t)LDS_PTR(smem);
+  // fragment j of 12 of the stage in slot r_slot: j < 4: weights (ni = j & 1, k16 step j >> 1), else activations
+  auto read_frag = [&](Frags& f, int j, int ab, int wb) {
+    if (j < 4) {
+      const int ni = j & 1, st = j >> 1;
+      f.w[ni][st] = *(lds_frag_ptr)(lbase + ((wb ^ (128 * (ni & 1) + 32 * st)) + 2048 * ni));
+    } else {
+      const int mi = (j - 4) & 3, st = (j - 4) >> 2;
+      f.a[mi][st] = *(lds_frag_ptr)(lbase + ((ab ^ (128 * (mi & 1) + 32 * st)) + 2048 * mi));
+    }
+  };
+  auto read_frags = [&](Frags& f) {
+    int ab = a_base0 + r_slot * PSTAGE, wb = w_base0 + r_slot * PSTAGE;
+    asm volatile("" : "+v"(ab), "+v"(wb));
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) aoff[mi][s] = p_img_off(grp * 128 + mi * 32 + l31, 2 * s + h);
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) woff[ni][s] = PIMG + p_img_off(wc * 64 + ni * 32 + l31, 2 * s + h);
-  }
+    for (int j = 0; j < 12; ++j) read_frag(f, j, ab, wb);
+    r_slot = (r_slot + 1) & 3;
+  };
 
   f32x16_t acc[2][4];                            // [ni][mi]
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  Frags fx, fy;
 
-  const int nk = k / PBK;                        // >= 24
-  PP_STAGE(0, 0);
-  PP_STAGE(1, 1);
-  PP_STAGE(2, 2);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this wave's pieces of stage 0
-  PP_BARRIER();                                        // ... everybody's
-  if (grp == 1) PP_BARRIER();                          // group 1 runs one barrier behind
-  int buf = 0;
-  s16x8_t af[4][2], wf[2][2];
-  [[maybe_unused]] unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-  if constexpr (PV_STAMPS) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
-  for (int t = 0; t < nk; ++t) {
-    // ---- load segment: fragments of stage t, requests for stage t + 3, wait for this wave's pieces of stage t + 1 ----
-    const char* st = smem + (PV_NO_READS ? 0 : buf) * PSTAGE;
-    if (!PV_NO_READS || t == 0)
+  // One stage p of the stream: the barrier that publishes stage p + 1 and retires stage p's slot, then 16 MFMAs on the
+  // fragments of stage p (cur) with, pinned behind them, the 12 fragment reads of stage p + 1 (-> nxt) and this wave's 4
+  // LDS-DMA pieces of stage p + 4 (into stage p's slot), then the counted wait for its pieces of stage p + 2.
+  // more: the stream has a next stage; sb: buffer stores issued between the previous stage and this one (a tile's epilogue).
+  auto stage = [&](const Frags& cur, Frags& nxt, bool more, bool sb) {
+    PP_BARRIER();
+    __builtin_amdgcn_sched_barrier(0);
+    int ab = a_base0 + r_slot * PSTAGE, wb = w_base0 + r_slot * PSTAGE;
+    asm volatile("" : "+v"(ab), "+v"(wb));
+    bool iss = false;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) wf[ni][s] = *reinterpret_cast<const s16x8_t*>(st + woff[ni][s]);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[mi][s] = *reinterpret_cast<const s16x8_t*>(st + aoff[mi][s]);
+    for (int j = 0; j < 16; ++j) {
+      const int st = j >> 3, ni = (j >> 2) & 1, mi = j & 3;
+      acc[ni][mi] = mfma32<DT>(cur.w[ni][st], cur.a[mi][st], acc[ni][mi]);
+      // the fragment order of the reads follows the order the NEXT stage's MFMAs need them in: w(0,0) a(0..3,0) w(1,0) ...
+      constexpr int order[12] = {0, 4, 5, 6, 7, 1, 2, 8, 9, 10, 11, 3};
+      if (j < 12 && more && !PV_NO_READS) read_frag(nxt, order[j], ab, wb);
+      if ((j & 3) == 3 && !PV_NO_DMA) iss = dma_piece(j >> 2);
+      if (!PV_NO_PIN) __builtin_amdgcn_sched_barrier(0);
     }
-    const int nb = buf == 0 ? 3 : buf - 1;             // the slot of stage t - 1 = (t + 3) % 4
-    if (PV_NO_DMA) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (PV_SPLIT_DMA) {
-      // (the two weight pieces of stage t + 3 go out at the head of the MFMA segment: the counted waits see 2 pieces fewer
-      // of the newest stage here and the same numbers otherwise)
-      if (t + 3 < nk) { PP_STAGE_A(t + 3, nb); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-      else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (t + 3 < nk) {
-      PP_STAGE(t + 3, nb);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // all but stages t + 2, t + 3
-    } else if (t + 2 < nk) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // all but stage t + 2
+    if (more) r_slot = (r_slot + 1) & 3;
+    __builtin_amdgcn_sched_barrier(0);
+    // this wave's pieces of stage p + 2 have landed: all but the 8 youngest (+ the stores of an epilogue in between)
+    if (iss) {
+      if (sb) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 + SPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    PP_T(0)                                            // reads issued + DMA issued + counted wait
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    PP_T(1)                                            // fragments arrived
-    PP_BARRIER();
-    PP_T(2)                                            // waited at the barrier that closes the load segment
-    // ---- MFMA segment ----
-    __builtin_amdgcn_sched_barrier(0);
-    if (PV_SPLIT_DMA && !PV_NO_DMA && t + 3 < nk) PP_STAGE_W(t + 3, nb);
-    if (!PV_NO_PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma32<DT>(wf[ni][s], af[mi][s], acc[ni][mi]);
-    if (!PV_NO_PRIO) __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    PP_T(3)                                            // 16 MFMAs issued
-    PP_BARRIER();
-    PP_T(4)                                            // waited at the barrier that closes the MFMA segment
-    buf = buf == 3 ? 0 : buf + 1;
-  }
-  if (grp == 0) PP_BARRIER();                          // (the barrier group 1 spent up front)
-#undef PP_STAGE
-#undef PP_STAGE_A
-#undef PP_STAGE_W
-#if PP_VARIANT & 64
-  if (blockIdx.x >= 8 && blockIdx.x < 16 && lane == 0) {     // (second round of XCD 0..7's first workgroups? no: blocks 8..15)
-    unsigned long long t_;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
-    for (int q = 0; q < 5; ++q) g_pp_stamps[blockIdx.x - 8][wave][q] = tacc[q];
-    g_pp_stamps[blockIdx.x - 8][wave][5] = t_;
-  }
-#endif
-  if constexpr (PV_NO_EPI) {                           // (timing-only: keep the accumulators alive)
-    float sink = 0.f;
+  };
+
+  // ---- prologue: four stages requested, the first two landed; the first stage's fragments ----
+  dma_next(); dma_next(); dma_next(); dma_next();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  PP_BARRIER();
+  read_frags(fx);
+
+  int c_vb = blockIdx.x;
+  bool first_tile = true;
+  for (;;) {
+    int64_t m0; int n0;
+    tile_origin(c_vb, m0, n0);
+    const bool last_tile = c_vb + G >= total_tiles;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sink += acc[i][j][r];
-    if (sink == 1.2345f) reinterpret_cast<float*>(out)[tid] = sink;
-    return;
-  }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    stage(fx, fy, true, !first_tile);
+    stage(fy, fx, true, !first_tile);
+    for (int t = 2; t < nk - 2; t += 2) {
+      stage(fx, fy, true, false);
+      stage(fy, fx, true, false);
+    }
+    stage(fx, fy, true, false);
+    stage(fy, fx, !last_tile, false);
+    first_tile = false;
+    PP_BARRIER();                                // (every wave is past the tile's last MFMA and fragment read)
 
-  // ---- epilogue: the accumulators hold C^T -- a lane owns activation row (per mi) and columns 32 ni + 8 g + 4 h + {0..3}.
-  //      The ring is dead (the last fragment reads finished in front of a barrier everybody has passed). ----
-  if constexpr (EPI == VITTF_EPI_BIAS_RESIDUAL) {
-    // fp32 read-modify-write of the residual stream: four passes of 128 rows x 128 columns (512-byte row segments)
-    float* xo = reinterpret_cast<float*>(out);
+    // ---- epilogue: the accumulators hold C^T -- a lane owns activation row (per mi) and columns 32 ni + 8 g + 4 h + {0..3} ----
+    if constexpr (PV_NO_EPI) {
+      float sink = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sink += acc[i][j][r];
+      if (sink == 1.2345f) reinterpret_cast<float*>(out)[tid] = sink;
+    } else {
+      // The tile leaves in eight parts of 32 rows x 256 columns.  Writers (the four waves of the part's group) put their raw
+      // fp32 accumulators into the staging area a row per lane (16-byte chunk index XOR row: conflict-free both ways); after
+      // the barrier ALL eight waves pick the part up as 1 KB row segments -- a thread owns four columns of four rows -- add
+      // the bias, apply the epilogue's function and send the result off: 512-byte runs of 16-bit values, or the fp32
+      // read-modify-write of the residual stream (x of a part is requested before the part is staged).  Always four buffer
+      // stores per thread and part (rows past the end fall outside the descriptor): the counted waits of the next tile's
+      // first stage know the number.
+      char* stg = smem + PRING;
+      constexpr bool RES = EPI == VITTF_EPI_BIAS_RESIDUAL;
+      // residual: a thread owns 4 columns (one staged chunk) of 4 rows; 16-bit outputs: 8 columns (two chunks -> one 16-byte
+      // store: the epilogue is bound by the NUMBER of store instructions) of 2 rows
+      const int ch = RES ? (tid & 63) : 2 * (tid & 31);
+      const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + 4 * ch);
+      [[maybe_unused]] const float4 bw = RES ? bv : *reinterpret_cast<const float4*>(bias + n0 + 4 * ch + 4);
+      [[maybe_unused]] const float qs = (n0 + 4 * ch) < n / 3 ? 0.125f * 1.44269504088896340736f : 1.0f;
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-      const int pg = pass >> 1, pc = pass & 1;         // row half, column half
-      if (pass) PP_BARRIER();
-      if (grp == pg && (wc >> 1) == pc) {
+      for (int sp = 0; sp < 8; ++sp) {
+        const int pg = sp >> 2, pm = sp & 3;
+        const int64_t row0 = m0 + pg * 128 + pm * 32;
+        const int64_t left = rows - row0;
+        const int vr = left <= 0 ? 0 : left < 32 ? (int)left : 32;
+        constexpr int ES = RES ? 4 : 2;
+        // (K features: CLS rows dropped, the others move up -- infer.py:202 k[:, 1:] --: per-lane output row, one descriptor
+        //  over the whole output, 32-bit byte offsets checked by the launcher, dropped rows get an offset outside it)
+        const auto rs = EPI == VITTF_EPI_KFEAT
+            ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(out), 0, (int)out_bytes, 0x00020000)
+            : __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(out) + (vr ? (row0 * n + n0) * ES : 0), 0,
+                                                vr ? ((vr - 1) * n + PBN) * ES : 0, 0x00020000);
+        [[maybe_unused]] pu32x4_t xv[4];
+        if constexpr (RES) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const int ml = mi * 32 + l31;
+          for (int i = 0; i < 4; ++i) xv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((i * 8 + (tid >> 6)) * n + 4 * ch) * 4, 0, 0);
+        }
+        if (grp == pg) {
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
+          for (int mi = 0; mi < 4; ++mi) {
+            if (mi != pm) continue;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int nl = (wc & 1) * 64 + ni * 32 + 8 * g + 4 * h;     // column inside this 128-wide half
-              const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + pc * 128 + nl);
-              float4 v;
-              v.x = acc[ni][mi][4 * g + 0] + bv.x; v.y = acc[ni][mi][4 * g + 1] + bv.y;
-              v.z = acc[ni][mi][4 * g + 2] + bv.z; v.w = acc[ni][mi][4 * g + 3] + bv.w;
-              *reinterpret_cast<float4*>(smem + ml * PCS + nl * 4) = v;
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int nl = wc * 64 + ni * 32 + 8 * g + 4 * h;
+                const float4 v = make_float4(acc[ni][mi][4 * g + 0], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
+                *reinterpret_cast<float4*>(stg + l31 * 1024 + (((nl >> 2) ^ l31) << 4)) = v;
+              }
             }
           }
         }
-      }
-      PP_BARRIER();
+        PP_BARRIER();
+        if constexpr (RES) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rl = i * 16 + (tid >> 5);            // 32 lanes per row: 512 bytes
-        const int64_t m = m0 + pg * 128 + rl;
-        if (m >= rows) continue;
-        const float4 d = *reinterpret_cast<const float4*>(smem + rl * PCS + (tid & 31) * 16);
-        float4* p = reinterpret_cast<float4*>(xo + m * n + n0 + pc * 128 + (tid & 31) * 4);
-        float4 x = *p;
-        x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
-        *p = x;
-      }
-    }
-  } else {
-    // 16-bit outputs: two passes of 128 rows x 256 columns (512-byte row segments)
-    unsigned short* o16 = reinterpret_cast<unsigned short*>(out);
-#pragma unroll 1
-    for (int pg = 0; pg < 2; ++pg) {
-      if (pg) PP_BARRIER();
-      if (grp == pg) {
+          for (int i = 0; i < 4; ++i) {
+            const int rl = i * 8 + (tid >> 6);
+            const float4 d = *reinterpret_cast<const float4*>(stg + rl * 1024 + ((ch ^ rl) << 4));
+            float4 x = __builtin_bit_cast(float4, xv[i]);
+            x.x += d.x + bv.x; x.y += d.y + bv.y; x.z += d.z + bv.z; x.w += d.w + bv.w;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4_t, x), rs, (rl * n + 4 * ch) * 4, 0, 0);
+          }
+        } else {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const int ml = mi * 32 + l31;
+          for (int i = 0; i < 2; ++i) {
+            const int rl = i * 16 + (tid >> 5);
+            const float4 d0 = *reinterpret_cast<const float4*>(stg + rl * 1024 + ((ch ^ rl) << 4));
+            const float4 d1 = *reinterpret_cast<const float4*>(stg + rl * 1024 + (((ch + 1) ^ rl) << 4));
+            float v[8] = {d0.x + bv.x, d0.y + bv.y, d0.z + bv.z, d0.w + bv.w, d1.x + bw.x, d1.y + bw.y, d1.z + bw.z, d1.w + bw.w};
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
+            for (int e = 0; e < 8; ++e) {
+              if constexpr (EPI == VITTF_EPI_BIAS_GELU) v[e] = gelu_poly(v[e]);
+              if constexpr (EPI == VITTF_EPI_BIAS_QKV) v[e] *= qs;   // the q third: softmax scale and exp -> exp2 base change
+            }
+            pu32x4_t pk;
+            if constexpr (EPI == VITTF_EPI_KFEAT) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int nl = wc * 64 + ni * 32 + 8 * g + 4 * h;
-              const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + nl);
-              float v0 = acc[ni][mi][4 * g + 0] + bv.x;
-              float v1 = acc[ni][mi][4 * g + 1] + bv.y;
-              float v2 = acc[ni][mi][4 * g + 2] + bv.z;
-              float v3 = acc[ni][mi][4 * g + 3] + bv.w;
-              if constexpr (EPI == VITTF_EPI_BIAS_GELU) {
-                v0 = gelu_poly(v0); v1 = gelu_poly(v1); v2 = gelu_poly(v2); v3 = gelu_poly(v3);
-              }
-              if constexpr (EPI == VITTF_EPI_BIAS_QKV) {
-                // the q third carries the softmax scale and the exp -> exp2 base change: one rounding, like plain q
-                const float sc = (n0 + nl) < n / 3 ? 0.125f * 1.44269504088896340736f : 1.0f;
-                v0 *= sc; v1 *= sc; v2 *= sc; v3 *= sc;
-              }
-              uint2 pk;
-              if constexpr (EPI == VITTF_EPI_KFEAT) {
-                pk.x = pack2_h16<VITTF_FP16>(v0, v1);
-                pk.y = pack2_h16<VITTF_FP16>(v2, v3);
-              } else {
-                pk.x = pack2_h16<DT>(v0, v1);
-                pk.y = pack2_h16<DT>(v2, v3);
-              }
-              *reinterpret_cast<uint2*>(smem + ml * PCS + nl * 2) = pk;
+              for (int e = 0; e < 4; ++e) pk[e] = pack2_h16<VITTF_FP16>(v[2 * e], v[2 * e + 1]);
+              const int64_t m = row0 + rl;
+              const int64_t b = m / tokens;
+              const int tok = (int)(m - b * tokens);
+              const int64_t orow = b * (tokens - 1) + tok - 1;
+              const unsigned off = (m < rows && tok != 0) ? (unsigned)((orow * n + n0 + 4 * ch) * 2) : 0xffffffffu;
+              __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (int)off, 0, 0);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) pk[e] = pack2_h16<DT>(v[2 * e], v[2 * e + 1]);
+              __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (rl * n + 4 * ch) * 2, 0, 0);
             }
           }
         }
-      }
-      PP_BARRIER();
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rl = i * 16 + (tid >> 5);            // 32 lanes per row: 512 bytes
-        const int64_t m = m0 + pg * 128 + rl;
-        if (m >= rows) continue;
-        int64_t orow = m;
-        if constexpr (EPI == VITTF_EPI_KFEAT) {
-          const int64_t b = m / tokens;
-          const int tok = (int)(m - b * tokens);
-          if (tok == 0) continue;                      // CLS row dropped (infer.py:202 k[:, 1:])
-          orow = b * (tokens - 1) + tok - 1;
-        }
-        const uint4 v = *reinterpret_cast<const uint4*>(smem + rl * PCS + (tid & 31) * 16);
-        *reinterpret_cast<uint4*>(o16 + orow * n + n0 + (tid & 31) * 8) = v;
+        PP_BARRIER();
       }
     }
+    if (last_tile) break;
+    c_vb += G;
   }
 }
 
@@ -325,12 +331,22 @@ int launch_pp(const void* a, const void* w, const float* bias, void* out, int64_
   const int64_t total64 = m_tiles * n_tiles;
   if (total64 > 0x7fffffff) return VITTF_ERR_INVALID_ARG;
   const int total = (int)total64;
+  const int cus = vittf_current_cus();
+  if (cus <= 0) return VITTF_ERR_NO_DEVICE;
+  // persistent: one workgroup per CU; the stride between a workgroup's tiles must keep it on its XCD (xcd_remap)
+  const int grid = total < cus ? total : (cus & ~7) ? (cus & ~7) : cus;
+  unsigned out_bytes = 0;
+  if (epi == VITTF_EPI_KFEAT) {
+    const int64_t ob = (rows - rows / tokens) * (int64_t)n * 2;
+    if (ob > 0xfffffff0ll) return 1;             // (32-bit byte offsets in that epilogue: the caller's other kernel takes it)
+    out_bytes = (unsigned)ob;
+  }
   const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Wp = (const unsigned short*)w;
 #define VITTF_PP_CASE(E)                                                                                              \
   case E:                                                                                                             \
-    hipLaunchKernelGGL((gemm_pp_kernel<DT, E>), dim3(total), dim3(512), 0, st, A, Wp, bias, out, rows, n, k, tokens,  \
-                       n_tiles, total);                                                                               \
+    hipLaunchKernelGGL((gemm_pp_kernel<DT, E>), dim3(grid), dim3(512), 0, st, A, Wp, bias, out, rows, n, k, tokens,   \
+                       n_tiles, total, out_bytes);                                                                    \
     break;
   switch (epi) {
     VITTF_PP_CASE(VITTF_EPI_BIAS)
@@ -349,11 +365,6 @@ int launch_pp(const void* a, const void* w, const float* bias, void* out, int64_
 #ifdef PP_STANDALONE      // tools/pp_variants.sh builds this file alone
 void vittf_note_kernel(int, const char*) {}
 #endif
-#if PP_VARIANT & 64
-extern "C" int vittf_pp_stamps(unsigned long long* out) {      // [8][8][6], host memory
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), sizeof(g_pp_stamps)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 // 1 = shape not covered (the caller falls back to gemm.hip's 128 x 128 tiles)
 #ifdef PP_STANDALONE
@@ -361,8 +372,8 @@ extern "C"
 #endif
 int vittf_gemm_pp(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
                   int32_t epilogue, int32_t tokens, int32_t dtype, hipStream_t st) {
-  if (k < 768 || k % PBK != 0 || n % PBN != 0) return 1;
-  if ((int64_t)k * 2 * PBM > 0x7fffffff) return 1;      // per-lane source offsets are 32-bit
+  if (k < 768 || k % (2 * PBK) != 0 || n % PBN != 0) return 1;
+  if ((int64_t)k * 2 * PBM > 0x7fffffff || (int64_t)n * 4 * 64 > 0x7fffffff) return 1;      // per-lane offsets are 32-bit
   if ((((uintptr_t)a | (uintptr_t)w | (uintptr_t)out) & 15) != 0) return 1;
   vittf_note_kernel(VITTF_KERNEL_GEMM, "gemm_pp_kernel");
   if (dtype == VITTF_BF16) return launch_pp<VITTF_BF16>(a, w, bias, out, rows, n, k, epilogue, tokens, st);
