@@ -55,6 +55,11 @@ constexpr bool PV_NO_DMA = PP_VARIANT & 1;       // no LDS-DMA inside the K loop
 constexpr bool PV_NO_READS = PP_VARIANT & 4;     // no fragment reads inside the K loop (wrong results)
 
 constexpr bool PV_NO_EPI = PP_VARIANT & 32;      // no epilogue (wrong results)
+// cache policy bits of the epilogue's 16-bit buffer stores: non-temporal (bit 1) by default -- the 128 KB a tile writes do not
+// push the operand panels the next tiles re-read out of L2: +3.5-4 % on qkv / fc1 (profiles/r04e_gemm_pp_store_policy.txt: 871 ->
+// 902, 787 -> 818 TFLOP/s); variants 512 / 1024 / 2048 = plain / sc0 nt / sc0 sc1.  The fp32 residual stores stay plain (no
+// difference measured, and the LayerNorm launch behind fc2 re-reads those rows).
+constexpr int PV_ST_AUX = (PP_VARIANT & 512) ? 0 : (PP_VARIANT & 1024) ? 3 : (PP_VARIANT & 2048) ? 17 : 2;
 constexpr bool PV_NO_PIN = PP_VARIANT & 128;     // no scheduling fences inside the MFMA segment (the compiler places the reads)
 
 // byte offset of 16-byte k-chunk kc (0..3) of row r inside a [R][32] operand image (two rows per 128-byte tile_off row)
@@ -80,13 +85,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
   constexpr int SPT = EPI == VITTF_EPI_BIAS_RESIDUAL ? 32 : 16;
 
   // ---- LDS-DMA: chunk q = i * 512 + tid of an image <- (row, k chunk) by the inverse of p_img_off; 2 + 2 pieces per wave ----
-  int voff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  // (chunk q + 512 is 128 image rows further on with the same swizzle: one per-lane offset, the rest is scalar)
+  int voff0;
+  {
     int dr, c;
-    tile_pos(i * 512 + tid, dr, c);
-    voff[i] = (2 * dr + (c >> 2)) * k * 2 + (c & 3) * 16;
+    tile_pos(tid, dr, c);
+    voff0 = (2 * dr + (c >> 2)) * k * 2 + (c & 3) * 16;
   }
+  const int piece_rows = 128 * k * 2;
   const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(smem);
   const unsigned dma_wave = ring_lds + wave * 1024;
 
@@ -113,11 +119,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
     if (!d_live) return false;
     const unsigned dst = dma_wave + d_slot * PSTAGE;
     const int so = d_k * (PBK * 2);
-    if (i == 0) lds_dma16(d_ra, dst, voff[0], so);
-    else if (i == 1) lds_dma16(d_ra, dst + 8192, voff[1], so);
-    else if (i == 2) lds_dma16(d_rw, dst + PIMG, voff[0], so);
+    if (i == 0) lds_dma16(d_ra, dst, voff0, so);
+    else if (i == 1) lds_dma16(d_ra, dst + 8192, voff0, so + piece_rows);
+    else if (i == 2) lds_dma16(d_rw, dst + PIMG, voff0, so);
     else {
-      lds_dma16(d_rw, dst + PIMG + 8192, voff[1], so);
+      lds_dma16(d_rw, dst + PIMG + 8192, voff0, so + piece_rows);
       d_slot = (d_slot + 1) & 3;
       if (++d_k == nk) {
         d_k = 0;
@@ -307,11 +313,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
               const int tok = (int)(m - b * tokens);
               const int64_t orow = b * (tokens - 1) + tok - 1;
               const unsigned off = (m < rows && tok != 0) ? (unsigned)((orow * n + n0 + 4 * ch) * 2) : 0xffffffffu;
-              __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (int)off, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (int)off, 0, PV_ST_AUX);
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e) pk[e] = pack2_h16<DT>(v[2 * e], v[2 * e + 1]);
-              __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (rl * n + 4 * ch) * 2, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (rl * n + 4 * ch) * 2, 0, PV_ST_AUX);
             }
           }
         }
