@@ -104,6 +104,9 @@ __device__ unsigned long long g_mlp_stamps[4 /*workgroups*/][4 /*tiles*/][4 /*wa
 #else
 #define MLP_STAMP(k)
 #endif
+// cache policy of the ROW traffic (a / x in, x / h out: every byte is used once): MLP_VARIANT & 128 = non-temporal, so that
+// the 4.8 GB a launch streams do not push the 2.65 MB of weights every CU keeps re-reading out of L2 (timing experiment)
+constexpr int RT_AUX = (MLP_VARIANT & 128) ? 2 : 0;
 constexpr bool V_NO_DMA = MLP_VARIANT & 1, V_M0_KEEP = MLP_VARIANT & 2 /* here: save + restore M0 */, V_NO_REFILL = MLP_VARIANT & 4, V_NO_GELU = MLP_VARIANT & 8,
                V_NO_XREQ = MLP_VARIANT & 32 /* projection units: no residual chunk requests */, V_NO_XFOLD = MLP_VARIANT & 64 /* ... no staging / adds */;
 
@@ -200,7 +203,7 @@ __device__ __forceinline__ void proj_unit(Stream& st, unsigned (&base)[4], s16x8
       }
       if constexpr (REQ && !V_NO_XREQ)
         if (j >= 18 && j < 22)
-          xi[(OT - 1) % XA][j - 18] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo + (OT - 1 + XA) * 128, (j - 18) * 8 * (D * 4), 0);
+          xi[(OT - 1) % XA][j - 18] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo + (OT - 1 + XA) * 128, (j - 18) * 8 * (D * 4), RT_AUX);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
   {
     const auto rs = tile_rsrc(abuf, tile, D * 2);
 #pragma unroll
-    for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (wave * 32 + l31) * (D * 2) + 16 * h, 32 * s, 0));
+    for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (wave * 32 + l31) * (D * 2) + 16 * h, 32 * s, RT_AUX));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first AHEAD images have landed (only here: the unit waits count
   __syncthreads();                                       // on a steady stream) ... everybody's pieces; the constants are written
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
 #pragma unroll
     for (int c = 0; c < XA; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xin[c][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo0 + c * 128, i * 8 * (D * 4), 0);
+      for (int i = 0; i < 4; ++i) xin[c][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo0 + c * 128, i * 8 * (D * 4), RT_AUX);
   }
 
   [[maybe_unused]] int tile_no = -1;
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
     const int hfo = (wave * 32 + (le & 31)) * (D * 2) + 16 * (le >> 5);
     auto request_next_fragments = [&] {
 #pragma unroll
-      for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(io.h_next, hfo, 32 * s, 0));
+      for (int s = 0; s < D / 16; ++s) hf[s] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(io.h_next, hfo, 32 * s, RT_AUX));
     };
     if constexpr (TAIL) {       // (the MLP alone: behind the residual pass, whose chunk registers they would spill)
       request_next_fragments();
@@ -528,13 +531,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
 #pragma unroll
       for (int c = 0; c < XA; ++c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xin[c][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo_e + c * 128, i * 8 * (D * 4), 0);
+        for (int i = 0; i < 4; ++i) xin[c][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo_e + c * 128, i * 8 * (D * 4), RT_AUX);
     }
     constexpr int XE = 3;      // (the MLP alone: residual tiles requested ahead in the epilogue)
     [[maybe_unused]] u32x4_t xi[XE][4];
     auto x_request = [&](int ot) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xi[ot % XE][i] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo_e + ot * 128, i * 8 * (D * 4), 0);
+      for (int i = 0; i < 4; ++i) xi[ot % XE][i] = __builtin_amdgcn_raw_buffer_load_b128(io.x, xo_e + ot * 128, i * 8 * (D * 4), RT_AUX);
     };
     if constexpr (!TAIL) {
 #pragma unroll
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f32x4_t v = *(lds_f4_ptr)(stg_rd_e + i * 8 * STG_ROW);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.x, xo_e + ot * 128, i * 8 * (D * 4), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.x, xo_e + ot * 128, i * 8 * (D * 4), RT_AUX);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const f32x4_t v = *(lds_f4_ptr)(stg_rd_e + i * 8 * STG_ROW);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.h_out, ho + op * 128, i * 8 * (D * 2), 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.h_out, ho + op * 128, i * 8 * (D * 2), RT_AUX);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
