@@ -19,16 +19,15 @@ def main():
     rows, d = batch * 4097, 768
     dev = torch.device('cuda', 0)
     g = torch.Generator().manual_seed(0)
-    libs = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'micro', 'build', 'libpp*_v*.so')),
-                  key=lambda p: ('pp2_' in p, int(re.search(r'_v(\d+)', p).group(1))))
+    libs = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'micro', 'build', 'libpp_v*.so')),
+                  key=lambda p: int(re.search(r'_v(\d+)', p).group(1)))
     fns = []
     for p in libs:
         lib = ctypes.CDLL(p)
-        two = 'libpp2_' in p
-        f = lib.vittf_gemm_pp2 if two else lib.vittf_gemm_pp
+        f = lib.vittf_gemm_pp
         f.restype = ctypes.c_int
         f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_int32] * 5 + [ctypes.c_void_p]
-        fns.append((('2:' if two else '') + re.search(r'_v(\d+)\.so', p).group(1), f))
+        fns.append((re.search(r'_v(\d+)\.so', p).group(1), f))
     for name, n, k, epi in (('qkv', 3 * d, d, 4), ('fc1+gelu', 4 * d, d, 1), ('fc2+res', d, 4 * d, 2)):
         a = torch.randn(rows, k, generator=g).half().to(dev)
         w = (torch.randn(n, k, generator=g) / k ** 0.5).half().to(dev)
@@ -39,7 +38,7 @@ def main():
             rc = f(a.data_ptr(), w.data_ptr(), bias.data_ptr(), o.data_ptr(), rows, n, k, epi, 4097, _lib.DTYPES['fp16'],
                    _lib.stream_ptr())
             assert rc == 0, rc
-        todo = [(v, f) for v, f in fns if not (v.startswith('2:') and epi == 2)]       # (gemm_pp2 has no residual epilogue)
+        todo = fns
         for _, f in todo:
             for _ in range(3):
                 run(f)
@@ -56,17 +55,6 @@ def main():
                 eb.record(); torch.cuda.synchronize()
                 ms = ea.elapsed_time(eb) / 10
                 print(f'{name:9s} round {rnd} variant {v:>5s}: {ms:.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s', flush=True)
-                if False:
-                    import numpy as np
-                    lib = ctypes.CDLL([p for p in libs if p.endswith(f'_v{v}.so')][0])
-                    buf = np.zeros((8, 8, 6), np.uint64)
-                    assert lib.vittf_pp_stamps(ctypes.c_void_p(buf.ctypes.data)) == 0
-                    names = ['load issue + counted wait', 'fragments arrive', 'barrier after load', '16 MFMAs issued', 'barrier after MFMA']
-                    for wg in (0, 3):
-                        for w in (0, 4):
-                            c = buf[wg, w, :5].astype(np.int64)
-                            print(f'   wg {wg} wave {w} ({k // 32} stages): ' + ', '.join(f'{n} {int(x) // (k // 32)}' for n, x in zip(names, c)) +
-                                  f' cycles per stage | K loop {int(c.sum())}', flush=True)
 
 
 if __name__ == '__main__':

@@ -1,33 +1,30 @@
-// Ping-pong MFMA GEMM for the long-K linears of ViT-B (D = 768: attn.qkv, attn.proj, mlp.fc1 + GELU, mlp.fc2):
+// Persistent 256 x 256 MFMA GEMM for the long-K linears of ViT-B (D = 768: attn.qkv, mlp.fc1 + GELU, mlp.fc2, K features):
 //     out = epilogue(A[rows][K] . W[N][K]^T + bias[N]),   K % 64 == 0, K >= 768, N % 256 == 0
 //
 // Round 4 (BASELINE configs[3]).  gemm.hip's 128 x 128 x 64 tiles (one stage, four workgroups per CU) run these shapes at
-// 740-870 TFLOP/s.  Two earlier forms of this file are in the history with their numbers: a pipelined
-// 256 x 128 kernel with two workgroups per CU (800: every wave alternates between memory issue and MFMA issue, and an LDS-DMA
-// piece costs 100+ issue cycles) and a first ping-pong kernel whose load segment carried the 12 fragment reads as well as
-// the 4 DMA pieces (800-870: stamps showed 700 cycles of load segment beside 560 of MFMA segment, and its epilogue -- 128 KB
-// of output per tile at the ~10 bytes per cycle a single workgroup's stores reach -- cost 24-32 % of the launch).  This form:
-//   * workgroup = 8 waves = 2 groups of 4 on a 256 x 256 output tile, persistent (one per CU); wave (g, c) owns rows
-//     128 g .. + 127 and columns 64 c .. + 63 = 4 x 2 accumulator tiles (128 VGPRs), computed transposed like the other GEMMs
-//     (weights = MFMA A operand, activations = B operand: a lane owns one activation row and 4 consecutive columns per
-//     register quad).  Waves w and w + 4 share a SIMD: the two groups are SIMD partners.
+// 740-870 TFLOP/s.  Earlier forms of this file are in the history with their numbers ("Round 4: the
+// ViT-B linears": a pipelined 256 x 128 kernel with two workgroups per CU; an 8-wave ping-pong kernel with a load segment
+// and an MFMA segment per K step -- hence the file's name; the same made persistent); timing-only builds of each
+// (tools/pp_variants.sh) said where its time went.  This form:
+//   * workgroup = 8 waves on a 256 x 256 output tile, persistent (one per CU); wave (g, c) owns rows 128 g .. + 127 and
+//     columns 64 c .. + 63 = 4 x 2 accumulator tiles (128 VGPRs), computed transposed like the other GEMMs (weights = MFMA A
+//     operand, activations = B operand: a lane owns one activation row and 4 consecutive columns per register quad).
 //   * a K step of 32 = a stage: [256][32] activation image + [256][32] weight image = 32 KB in the "double-row" layout of
 //     gemm_rows.hip (conflict-free ds_read_b128); 4-deep ring = 128 KB.  The stages of a workgroup's tiles form ONE stream:
 //     the ring never drains between tiles.
-//   * per stage p a wave runs a LOAD segment -- its 4 LDS-DMA pieces of stage p + 3 -- and an MFMA segment -- 16 MFMAs on the
-//     fragments of stage p with the 12 fragment reads of stage p + 1 between them (two fragment sets in registers; a
-//     ds_read_b128 in an MFMA gap is nearly free), then the counted wait for its pieces of stage p + 2 --, each closed by a
-//     workgroup barrier; group 1 runs one barrier behind group 0, so while one group's waves issue MFMAs their SIMD partners
-//     issue memory work.  0.75 LDS reads and 0.25 DMA pieces per MFMA.
-//   * hazards by construction: stage p + 1 is read in the MFMA segments of stage p (slots 2 p + 1 and 2 p + 2); every wave
-//     has waited for its pieces of stage p + 1 at the end of its MFMA segment of stage p - 1 (slots 2 p - 1, 2 p), in front
-//     of a barrier every reader passes first; the pieces of stage p + 3 overwrite the slot of stage p - 1, whose last read
-//     (slot 2 p - 2, lgkmcnt(0) in front of its closing barrier) precedes their issue (slots 2 p, 2 p + 1).
-//   * epilogue: the groups are brought level (one barrier), the tile leaves in eight parts of 32 rows through a 32 KB fp32
-//     staging area BEHIND the ring: four waves stage their accumulators, all eight apply bias / GELU / q scale (or the fp32
-//     residual read-modify-write) and issue whole-row-segment buffer stores that stay in flight under the next tile's K loop
-//     -- whose first three stages are already in the ring -- then group 1 drops one barrier behind again.  The counted waits
-//     know how many stores a tile leaves behind.
+//   * stage p = ONE barrier, then one pinned instruction stream (sched_barrier after every MFMA): 16 MFMAs on the fragments of
+//     stage p with, behind the first twelve, the 12 fragment reads of stage p + 1 (two fragment sets in registers; a
+//     ds_read_b128 in an MFMA gap is nearly free) and, behind every fourth, one of this wave's 4 LDS-DMA pieces of stage
+//     p + 4 -- into stage p's slot, which is free because its fragments already sit in registers --, then the counted wait
+//     for its pieces of stage p + 2.  0.75 LDS reads and 0.25 DMA pieces per MFMA.
+//   * hazards by construction: stage p + 1 is read during stage p; every wave has waited for its pieces of stage p + 1 at the
+//     end of stage p - 1 (they were requested during stage p - 3: two stages of slack), in front of the barrier that opens
+//     stage p; the pieces of stage p + 4 overwrite the slot of stage p, whose last read (during stage p - 1, lgkmcnt(0) in
+//     front of the same barrier) precedes their issue.
+//   * epilogue: the tile leaves in eight parts of 32 rows through a 32 KB fp32 staging area BEHIND the ring: four waves stage
+//     their accumulators, all eight apply bias / GELU / q scale (or the fp32 residual read-modify-write) and issue 16-byte
+//     buffer stores (non-temporal for 16-bit outputs) that stay in flight under the next tile's K loop -- whose first
+//     stages are already in the ring.  The counted waits of a tile's first two stages know how many stores lie in between.
 //   * a partial last row tile reads zeros for its missing rows (descriptor bounds) and drops their outputs: a row's bits do
 //     not depend on where it sits in a launch.
 #include "vittf_common.h"
