@@ -269,16 +269,32 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
   }
   int t = blockIdx.x;
   const int stride = gridDim.x;
-  if (t < ntiles) { SM_STAGE_ROWS(t, 0) SM_STAGE_ROWS(t, 1) }
-  // the query images (sim_mfma_prep's arithmetic): 32 rows x 48 chunks of 8 features, 3 chunks per thread; rows >= n_q are zero
+  // The query rows are requested AHEAD of the first volume parts, by loads hipcc does not see (round 4): its own wait for
+  // them would be vmcnt(0), i.e. it would also wait for the 8 LDS-DMA pieces of parts 0 and 1 -- the memory counter retires
+  // in order -- and the query images would only be built once 64 KB of volume had come in from HBM.  Issued first and waited
+  // for with a counted vmcnt(8), they arrive and are converted while the parts are still on their way.  A thread owns three
+  // of the 32 x 48 chunks of 8 features; rows >= n_q read row n_q - 1 and are zeroed.
+  f32x4_t qa[3], qb[3];
 #pragma unroll
-  for (int e = tid; e < 32 * 48; e += SM_THREADS) {
+  for (int i = 0; i < 3; ++i) {
+    const int e = tid + i * SM_THREADS;
     const int p = e / 48, c = e - 48 * p;
+    const float* src = qf + (int64_t)(p < n_q ? p : n_q - 1) * SM_F + 8 * c;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(qa[i]), "=&v"(qb[i]) : "v"(src) : "memory");
+  }
+  if (t < ntiles) { SM_STAGE_ROWS(t, 0) SM_STAGE_ROWS(t, 1) }
+  if (t < ntiles) asm volatile("s_waitcnt vmcnt(8)" : "+v"(qa[0]), "+v"(qb[0]), "+v"(qa[1]), "+v"(qb[1]), "+v"(qa[2]), "+v"(qb[2]) :: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa[0]), "+v"(qb[0]), "+v"(qa[1]), "+v"(qb[1]), "+v"(qa[2]), "+v"(qb[2]) :: "memory");
+  // the query images (sim_mfma_prep's arithmetic): 32 rows x 48 chunks of 8 features; rows >= n_q are zero
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = tid + i * SM_THREADS;
+    const int p = e / 48, c = e - 48 * p;
+    const float qv[8] = {qa[i][0], qa[i][1], qa[i][2], qa[i][3], qb[i][0], qb[i][1], qb[i][2], qb[i][3]};
     unsigned hi[4], lo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float q0 = 0.f, q1 = 0.f;
-      if (p < n_q) { q0 = qf[(int64_t)p * SM_F + 8 * c + 2 * j]; q1 = qf[(int64_t)p * SM_F + 8 * c + 2 * j + 1]; }
+      const float q0 = p < n_q ? qv[2 * j] : 0.f, q1 = p < n_q ? qv[2 * j + 1] : 0.f;
       const unsigned short h0 = f32_to_f16bits(q0), h1 = f32_to_f16bits(q1);
       const unsigned short l0 = f32_to_f16bits(q0 - f16bits_to_f32(h0)), l1 = f32_to_f16bits(q1 - f16bits_to_f32(h1));
       hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
