@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITTF_ABI_VERSION 4
+#define VITTF_ABI_VERSION 5
 
 typedef enum vittf_status {
   VITTF_OK = 0,
@@ -247,6 +247,20 @@ int64_t vittf_attention_rescale_count(int32_t reset);
 size_t vittf_attention_fp8_workspace_bytes(int32_t batch, int32_t tokens, int32_t heads);
 int vittf_attention_fp8(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype, void* ws,
                         size_t ws_bytes, void* stream);
+
+/* The same path with q and k quantised where they are produced (round 4; what the engine runs for embed_dim >= 768):
+ *   vittf_gemm_qkv_fp8: Attention.qkv (+ the q scale of VITTF_EPI_BIAS_QKV) for rows = batch * tokens rows, n = 3 * heads * 64,
+ *     n / 3 a multiple of 256, k >= 768 and a multiple of 64.  q and k leave as e4m3 bytes [slice][head][token][64] with one
+ *     power-of-two scale (E8M0 byte) per row and 32-wide block -- the MX block format: the matrix instruction's scale operand
+ *     is per lane, i.e. per row and block -- into `ws`; v is written as h16 into the v third of qkv_out [rows][n] (the q and k
+ *     thirds of qkv_out are NOT written) and its per-(slice, head) absolute maximum is collected into `ws`.
+ *   vittf_attention_fp8_rows: quantises + re-lays the v third (per-(slice, head) scale), then the attention kernel with the
+ *     row scales.  Same output contract and error class as vittf_attention_fp8 (finer scales for q and k).
+ * ws: the same vittf_attention_fp8_workspace_bytes(batch, tokens, heads) workspace, passed to both calls. */
+int vittf_gemm_qkv_fp8(const void* a, const void* w, const float* bias, void* qkv_out, int64_t rows, int32_t n, int32_t k,
+                       int32_t tokens, int32_t heads, int32_t dtype, void* ws, size_t ws_bytes, void* stream);
+int vittf_attention_fp8_rows(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype, void* ws,
+                             size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Feature-volume epilogue (infer.py:201-203 permute_out, :329 AdaptiveAvgPool3d, :330-332 axis sum).

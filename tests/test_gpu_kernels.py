@@ -1178,6 +1178,95 @@ def test_attention_fp8(gpu, dt, batch, tokens, heads):
                                    _lib.stream_ptr()) == -2      # workspace too small
 
 
+@pytest.mark.parametrize('dt', ['fp16', 'bf16'])
+@pytest.mark.parametrize('batch,tokens', [(1, 1), (3, 65), (2, 200), (1, 4097)])
+def test_qkv_fp8_rows_path(gpu, dt, batch, tokens):
+    """vittf_gemm_qkv_fp8 + vittf_attention_fp8_rows (ViT-B head count: 12 heads, K = 768): the qkv projection whose q and k
+    leave as e4m3 rows with one power-of-two scale per row and 32-wide block (the MX format of the matrix instruction's
+    scale operands), v as 16-bit values with its per-(slice, head) maximum collected on the way, then the attention kernel
+    with row scales.  Checked: (1) the v third of the qkv buffer = the plain GEMM's bits; (2) the attention output against
+    the exact fp64 attention of the exact fp64 projection (the path's stated 6e-2) and against a host model that rounds q and
+    k to e4m3 with per-row-block scales and v with its per-(slice, head) scale (2e-2); slices of 65 / 200 tokens put slice
+    boundaries inside the GEMM's 256-row tiles."""
+    lib = _lib.load()
+    heads, k = 12, 768
+    d = heads * 64
+    n = 3 * d
+    rows = batch * tokens
+    g = gen(tokens * 7 + batch)
+    a = torch.randn(rows, k, generator=g).to(TDT[dt])
+    w = (torch.randn(n, k, generator=g) / k ** 0.5)
+    w[:2 * d] *= 1.3
+    w[2 * d:] *= 2.0
+    w = w.to(TDT[dt])
+    bias = 0.2 * torch.randn(n, generator=g)
+    bias[2 * d:] += 0.5
+    ad, wd, bd = a.to(gpu), w.to(gpu), bias.to(gpu)
+    ws = torch.empty(lib.vittf_attention_fp8_workspace_bytes(batch, tokens, heads), dtype=torch.uint8, device=gpu)
+    qkv = torch.full((rows + 2, n), 7.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_gemm_qkv_fp8(_lib.ptr(ad), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(qkv), rows, n, k, tokens, heads,
+                                      _lib.DTYPES[dt], _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    out = torch.full((rows + 2, d), 7.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_attention_fp8_rows(_lib.ptr(qkv), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], _lib.ptr(ws),
+                                            ws.numel(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    # (1) the v third: the same bits as the plain qkv GEMM; nothing behind the last row, nothing in the q / k thirds
+    plain = torch.empty(rows, n, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_gemm(_lib.ptr(ad), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(plain), rows, n, k, _lib.EPI_BIAS_QKV, 0,
+                              _lib.DTYPES[dt], _lib.stream_ptr()))
+    assert torch.equal(qkv[:rows, 2 * d:], plain[:, 2 * d:])
+    assert (qkv[rows:].float() == 7.0).all() and (qkv[:rows, :2 * d].float() == 7.0).all()
+    got = out.float().cpu().double()
+    assert (got[rows:] == 7.0).all(), 'wrote past the last row'
+    got = got[:rows]
+    assert torch.isfinite(got).all()
+    # (2) exact reference: fp64 projection of the 16-bit operands (+ the q scale), fp64 attention
+    proj = (ad.double() @ wd.double().t() + bd.double()).cpu()
+    proj[:, :d] *= QSCALE
+    # (1b) what the GEMM left in the workspace (layout: attention_fp8.hip::fp8_ws -- amax | q8 | k8 | v8t | qs | ks): every q / k
+    # row de-quantised with its block scales is the projection to e4m3 precision (half an ulp of a 3-bit mantissa = 2^-4 of
+    # the block maximum at worst), and no block wastes more than one binade of the format's range
+    np_ = (tokens + 63) // 64 * 64
+    per = batch * heads * np_ * 64
+    off_q = (batch * heads * 12 + 255) // 256 * 256
+    off_qs = off_q + 3 * per
+    sc_bytes = (batch * heads * np_ * 2 + 255) // 256 * 256
+    wsc = ws.cpu()
+    for part, (o8, osc) in enumerate(((off_q, off_qs), (off_q + per, off_qs + sc_bytes))):
+        # a stored row is [d 0-15 | d 32-47 | d 16-31 | d 48-63]: the matrix instruction's MX block b of a row is bytes 16 b ..
+        # 16 b + 15 of both lane halves (tools/micro/mfma_f8_scale_probe2.hip), and lane half hh reads bytes 32 hh .. 32 hh + 31
+        q8 = wsc[o8:o8 + per].view(torch.float8_e4m3fn).to(torch.float64).view(batch, heads, np_, 2, 2, 16)[:, :, :tokens]
+        q8 = q8.permute(0, 1, 2, 4, 3, 5).reshape(batch, heads, tokens, 2, 32)            # (lane half, block, 16) -> (block, 32)
+        sc = wsc[osc:osc + batch * heads * np_ * 2].view(batch, heads, np_, 2)[:, :, :tokens].to(torch.float64)
+        deq = q8 * (2.0 ** (sc - 127.0))[..., None]                                   # (batch, heads, tokens, 2, 32)
+        want = proj.view(batch, tokens, 3, heads, 2, 32)[:, :, part].permute(0, 2, 1, 3, 4)
+        bmax = want.abs().amax(dim=-1, keepdim=True)
+        assert ((deq - want).abs() <= bmax * 2.0 ** -4 + 1e-6).all(), f'part {part}: de-quantised rows differ from the projection'
+        assert (q8.abs().amax(dim=-1) >= 224.0 * (bmax[..., 0] > 1e-6)).all(), f'part {part}: a block scale wastes range'
+    exact = _attn_ref(proj, batch, tokens, heads, 1)
+    # model: q, k rounded to e4m3 per (row, 32-wide block) with 2^e scales; v from its 16-bit values with the (slice, head) scale
+    x = proj.view(batch, tokens, 3, heads, 2, 32).clone()
+    for part in range(2):
+        t = x[:, :, part]                                          # (batch, tokens, heads, 2, 32)
+        amax = t.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+        e = torch.ceil(torch.log2(amax / 448.0))
+        e = torch.where(torch.log2(amax / 448.0) == e, e + 1, e).clamp_min(-20)
+        x[:, :, part] = _e4m3(t / 2.0 ** e) * 2.0 ** e
+    v16 = plain[:, 2 * d:].float().cpu().double().view(batch, tokens, heads, 64)
+    amax = v16.abs().amax(dim=(1, 3), keepdim=True).clamp_min(1e-30)
+    e = torch.ceil(torch.log2(amax / 448.0))
+    e = torch.where(torch.log2(amax / 448.0) == e, e + 1, e)
+    x[:, :, 2] = (_e4m3(v16 / 2.0 ** e) * 2.0 ** e).view(batch, tokens, heads, 2, 32)
+    model = _attn_ref(x.reshape(rows, 3 * d), batch, tokens, heads, 1)
+    e_exact, e_model = rel_fro(got, exact), rel_fro(got, model)
+    print(f'fp8 rows path {batch}x{tokens}x{heads} {dt}: rel fro {e_exact:.3e} vs exact, {e_model:.3e} vs the MX-operand model')
+    assert e_exact <= 6e-2 and e_model <= 2e-2
+    assert lib.vittf_gemm_qkv_fp8(_lib.ptr(ad), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(qkv), rows, n, k, tokens, heads,
+                                  _lib.DTYPES[dt], _lib.ptr(ws), 16, _lib.stream_ptr()) == -2      # workspace too small
+    assert lib.vittf_gemm_qkv_fp8(_lib.ptr(ad), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(qkv), rows, n, k, tokens, heads + 1,
+                                  _lib.DTYPES[dt], _lib.ptr(ws), ws.numel(), _lib.stream_ptr()) == -1     # n != 3 * heads * 64
+
+
 def test_non_finite_volume_is_refused(gpu):
     vol = torch.rand((8, 8, 8), generator=gen(1))
     vol[3, 4, 5] = float('nan')

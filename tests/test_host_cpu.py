@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/vittf.h but not exported by libvittf.so'
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.vittf_abi_version() == vt._lib.ABI_VERSION == 4
+    assert lib.vittf_abi_version() == vt._lib.ABI_VERSION == 5
     assert lib.vittf_status_string(-2) == b'workspace too small'
 
 

@@ -74,6 +74,8 @@ SIGNATURES = {
     'vittf_attention_rescale_count': (_i64, [_i32]),
     'vittf_attention_fp8_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'vittf_attention_fp8': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    'vittf_gemm_qkv_fp8': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    'vittf_attention_fp8_rows': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     'vittf_pool_slices': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64,
                                     _i64, _vp]),
     'vittf_assemble_sum': (C.c_int, [_vp, _vp, _vp, _i32, _P(_i32), _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -124,7 +126,7 @@ def load():
 
 KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention', 'mlp', 'gemm_qkv', 'gemm_proj', 'gemm_fc1', 'gemm_fc2',
                   'similarity')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def profiler_enable(on=True, classes=None):

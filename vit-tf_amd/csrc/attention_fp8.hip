@@ -25,6 +25,15 @@
 //      order they ARE the B operand of the output product if V^T's k slots are laid out to match:
 //          slot 32 h + 16 b + r  <->  key 32 b + (r & 3) + 8 (r >> 2) + 4 h        (done once, by launch 2)
 //      so every operand fragment of the kernel is 32 contiguous bytes: two ds_read_b128, no transposing reads.
+//
+// Round 4: a second operand preparation, for q / k that the qkv GEMM itself writes as fp8 (gemm_pp.hip, vittf_gemm_qkv_fp8):
+// the instruction's scale operands are per LANE, i.e. per row and 32-wide k block -- the MX block format -- so q and k rows
+// carry their own power-of-two scales ([slice][head][token][2] E8M0 bytes; the bytes of a row stored in the instruction's
+// block order [d 0-15 | d 32-47 | d 16-31 | d 48-63]: block b = bytes 16 b .. 16 b + 15 of both lane halves), computed where
+// the row is produced: no absmax
+// pass over q and k, no quantise pass, half the bytes out of the GEMM.  v keeps its per-(slice, head) scale (its 32-element
+// blocks run along the KEYS: they cross the rows a GEMM tile produces); its absmax comes from that GEMM's epilogue and only
+// the v third goes through the quantise + re-lay kernel (vittf_attention_fp8_rows).
 #include "attn_common.h"
 
 namespace {
@@ -145,6 +154,40 @@ __global__ __launch_bounds__(256) void quant_kernel(const unsigned short* __rest
   *reinterpret_cast<uint4*>(v8t + ((int64_t)bh * 64 + d) * np + tile * 64 + 16 * quarter) = o;
 }
 
+// ---------------------------------------------------------------- 2b. the v third alone (q / k arrive as fp8 from the GEMM)
+template <int DT>
+__global__ __launch_bounds__(256) void quant_v_kernel(const unsigned short* __restrict__ qkv, int tokens, int heads, int np,
+                                                      const unsigned* __restrict__ amax_bits, unsigned char* __restrict__ v8t) {
+  __shared__ __attribute__((aligned(16))) unsigned char vt[64][64 + 16];   // [dim][slot], padded rows
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int tid = threadIdx.x;
+  const int dmodel = heads * 64, ld = 3 * dmodel;
+  const int tile = blockIdx.x, kin = tid >> 2, quarter = tid & 3;
+  const int tok = tile * 64 + kin;
+  const float inv = ldexpf(1.0f, -scale_exp(__uint_as_float(amax_bits[bh * 3 + 2])));
+  unsigned w[4] = {0u, 0u, 0u, 0u};
+  if (tok < tokens) {
+    const unsigned short* row = qkv + ((int64_t)b * tokens + tok) * ld + 2 * dmodel + hd * 64 + 16 * quarter;
+    const s16x8_t v0 = *reinterpret_cast<const s16x8_t*>(row);
+    const s16x8_t v1 = *reinterpret_cast<const s16x8_t*>(row + 8);
+    float f[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] = h16_to_f32<DT>((unsigned short)v0[j]) * inv;
+      f[8 + j] = h16_to_f32<DT>((unsigned short)v1[j]) * inv;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = pack4_fp8(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]);
+  }
+  const int slot = vt_slot(kin);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) vt[16 * quarter + j][slot] = (unsigned char)(w[j >> 2] >> (8 * (j & 3)));
+  __syncthreads();
+  const int d = tid >> 2;
+  const uint4 o = *reinterpret_cast<const uint4*>(&vt[d][16 * quarter]);
+  *reinterpret_cast<uint4*>(v8t + ((int64_t)bh * 64 + d) * np + tile * 64 + 16 * quarter) = o;
+}
+
 // ---------------------------------------------------------------- 3. attention
 // LDS image of an operand tile: 64 rows (keys for K, dims for V^T) x 64 bytes, the four 16-byte chunks of row r stored at
 // chunk position c ^ ((r >> 2) & 3): the 16-lane groups of ds_read_b128 then hit distinct banks
@@ -159,11 +202,24 @@ __device__ __forceinline__ i32x8_t read_frag(const char* tile, int row, int hh) 
   return f;
 }
 
-template <int DT>
+// ROWSC: q and k carry one E8M0 scale byte per row and 32-wide k block (qs / ks: [slice][head][token][2]) instead of one
+// exponent per (slice, head): a lane's scale operand is then the byte of ITS row and block.
+// A per-lane scale operand, finished well ahead of the matrix instruction that reads it: hipcc folds the byte's zero extension
+// into a v_and_b32 right in front of the v_mfma_scale and leaves no wait states between the two -- with a uniform scale every
+// stale value is the right one, with per-row scales it is the previous tile's (found with host-made MX operands: 0.6
+// relative error from 64 tokens on, none with uniform bytes).  The mask and its wait states are one asm statement here.
+__device__ __forceinline__ int scale_operand(int raw) {
+  int r;
+  asm volatile("v_and_b32 %0, 0xff, %1\n\ts_nop 7" : "=v"(r) : "v"(raw));
+  return r;
+}
+
+template <int DT, bool ROWSC>
 __global__ __launch_bounds__(256, 3) void attn_fp8_kernel(const unsigned char* __restrict__ q8, const unsigned char* __restrict__ k8,
                                                           const unsigned char* __restrict__ v8t,
                                                           const unsigned* __restrict__ amax_bits, unsigned short* __restrict__ out,
-                                                          int tokens, int heads, int np, int q_tiles, int total) {
+                                                          int tokens, int heads, int np, int q_tiles, int total,
+                                                          const unsigned char* __restrict__ qs, const unsigned char* __restrict__ ks) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF_B];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
@@ -172,15 +228,21 @@ __global__ __launch_bounds__(256, 3) void attn_fp8_kernel(const unsigned char* _
   const int hd = bh % heads, b = bh / heads;
   const int dmodel = heads * 64;
 
-  const int eq = scale_exp(__uint_as_float(amax_bits[bh * 3 + 0]));
-  const int ek = scale_exp(__uint_as_float(amax_bits[bh * 3 + 1]));
+  const int eq = ROWSC ? 0 : scale_exp(__uint_as_float(amax_bits[bh * 3 + 0]));
+  const int ek = ROWSC ? 0 : scale_exp(__uint_as_float(amax_bits[bh * 3 + 1]));
   const int ev = scale_exp(__uint_as_float(amax_bits[bh * 3 + 2]));
-  const int sc_q = (127 + eq) * 0x01010101, sc_k = (127 + ek) * 0x01010101, sc_v = (127 + ev) * 0x01010101;
+  int sc_q = (127 + eq) * 0x01010101;
+  const int sc_k = (127 + ek) * 0x01010101, sc_v = (127 + ev) * 0x01010101;
   const int sc_p = (127 - P_HEADROOM_LOG2) * 0x01010101;
 
   // Q fragment (B operand): lane holds Q[row l31][32 hh .. +31]
   const int qrow = qt * QT + wave * 32 + l31;
   const int qrow_c = qrow < tokens ? qrow : tokens - 1;
+  if constexpr (ROWSC) sc_q = scale_operand((int)qs[((int64_t)bh * np + qrow_c) * 2 + hh]);      // this lane's row and block
+  // K scales: lane (l31, hh) of key block bk needs the byte of key 64 t + 32 bk + l31, block hh
+  const unsigned char* ksl = ROWSC ? ks + ((int64_t)bh * np + l31) * 2 + hh : nullptr;
+  int ksc[2] = {sc_k, sc_k};
+  if constexpr (ROWSC) { ksc[0] = scale_operand((int)ksl[0]); ksc[1] = scale_operand((int)ksl[64]); }
   i32x8_t qf;
   {
     const unsigned char* qp = q8 + ((int64_t)bh * np + qrow_c) * 64 + 32 * hh;
@@ -218,6 +280,10 @@ __global__ __launch_bounds__(256, 3) void attn_fp8_kernel(const unsigned char* _
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
+    int ksn[2] = {sc_k, sc_k};                  // the next tile's key scales (waited for with the tile's DMA below)
+    if constexpr (ROWSC) {
+      if (t + 1 < nt) { ksn[0] = (int)ksl[(t + 1) * 128]; ksn[1] = (int)ksl[(t + 1) * 128 + 64]; }
+    }
     if (active) {
       const char* kt = smem + buf * BUF_B;
       const char* vtile = kt + TILE_B;
@@ -225,7 +291,7 @@ __global__ __launch_bounds__(256, 3) void attn_fp8_kernel(const unsigned char* _
 #pragma unroll
       for (int bk = 0; bk < 2; ++bk) {
         const i32x8_t kf = read_frag(kt, 32 * bk + l31, hh);
-        s[bk] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, negm, 0, 0, 0, sc_k, 0, sc_q);
+        s[bk] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, negm, 0, 0, 0, ksc[bk], 0, sc_q);
       }
       if (t == nt - 1) {
 #pragma unroll
@@ -280,6 +346,7 @@ __global__ __launch_bounds__(256, 3) void attn_fp8_kernel(const unsigned char* _
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (ROWSC) { ksc[0] = scale_operand(ksn[0]); ksc[1] = scale_operand(ksn[1]); }
   }
   if (!active) return;
 
@@ -307,16 +374,19 @@ __global__ __launch_bounds__(256, 3) void attn_fp8_kernel(const unsigned char* _
   }
 }
 
-struct Fp8Ws { size_t amax, q8, k8, v8t, total; int np; };
+struct Fp8Ws { size_t amax, q8, k8, v8t, qs, ks, total; int np; };
 Fp8Ws fp8_ws(int batch, int tokens, int heads) {
   Fp8Ws w;
   w.np = (tokens + KT - 1) / KT * KT;
   const size_t per = (size_t)batch * heads * w.np * 64;
+  const size_t sc = ((size_t)batch * heads * w.np * 2 + 255) & ~(size_t)255;     // row scales (vittf_gemm_qkv_fp8)
   w.amax = 0;
   w.q8 = ((size_t)batch * heads * 3 * 4 + 255) & ~(size_t)255;
   w.k8 = w.q8 + per;
   w.v8t = w.k8 + per;
-  w.total = w.v8t + per;
+  w.qs = w.v8t + per;
+  w.ks = w.qs + sc;
+  w.total = w.ks + sc;
   return w;
 }
 
@@ -352,10 +422,53 @@ extern "C" int vittf_attention_fp8(const void* qkv, void* out, int32_t batch, in
     hipLaunchKernelGGL((absmax_kernel<DTV>), grid, dim3(256), 0, st, (const unsigned short*)qkv, tokens, heads, amax);  \
     hipLaunchKernelGGL((quant_kernel<DTV>), grid, dim3(256), 0, st, (const unsigned short*)qkv, tokens, heads, w.np,    \
                        amax, q8, k8, v8t);                                                                              \
-    hipLaunchKernelGGL((attn_fp8_kernel<DTV>), dim3(total), dim3(256), 0, st, q8, k8, v8t, amax, (unsigned short*)out,  \
-                       tokens, heads, w.np, q_tiles, total);                                                            \
+    hipLaunchKernelGGL((attn_fp8_kernel<DTV, false>), dim3(total), dim3(256), 0, st, q8, k8, v8t, amax,                 \
+                       (unsigned short*)out, tokens, heads, w.np, q_tiles, total, (const unsigned char*)nullptr,        \
+                       (const unsigned char*)nullptr);                                                                  \
   }
   if (dtype == VITTF_BF16) FP8_LAUNCH(VITTF_BF16) else FP8_LAUNCH(VITTF_FP16)
 #undef FP8_LAUNCH
+  return vittf_check_launch();
+}
+
+// Where vittf_gemm_qkv_fp8 (gemm_pp.hip) puts its outputs inside the workspace of this file (C++ linkage, not part of the ABI).
+void vittf_fp8_ws_pointers(void* ws, int32_t batch, int32_t tokens, int32_t heads, unsigned** amax, unsigned char** q8,
+                           unsigned char** k8, unsigned char** qs, unsigned char** ks, int32_t* np) {
+  const Fp8Ws w = fp8_ws(batch, tokens, heads);
+  char* base = (char*)ws;
+  *amax = (unsigned*)(base + w.amax); *q8 = (unsigned char*)(base + w.q8); *k8 = (unsigned char*)(base + w.k8);
+  *qs = (unsigned char*)(base + w.qs); *ks = (unsigned char*)(base + w.ks); *np = w.np;
+}
+
+extern "C" int vittf_attention_fp8_rows(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
+                                        void* ws, size_t ws_bytes, void* stream) {
+  vittf_note_kernel(VITTF_KERNEL_ATTENTION, "attn_fp8_kernel<row scales> (+ quantise v)");
+  if (!qkv || !out || !ws || batch <= 0 || tokens <= 0 || heads <= 0) return VITTF_ERR_INVALID_ARG;
+  if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
+  if (((uintptr_t)ws & 255) != 0) return VITTF_ERR_INVALID_ARG;
+  const Fp8Ws w = fp8_ws(batch, tokens, heads);
+  if (ws_bytes < w.total) return VITTF_ERR_WORKSPACE;
+  if ((int64_t)batch * heads > 65535) return VITTF_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)ws;
+  const unsigned* amax = (const unsigned*)(base + w.amax);
+  const unsigned char* q8 = (const unsigned char*)(base + w.q8);
+  const unsigned char* k8 = (const unsigned char*)(base + w.k8);
+  unsigned char* v8t = (unsigned char*)(base + w.v8t);
+  const unsigned char* qs = (const unsigned char*)(base + w.qs);
+  const unsigned char* ks = (const unsigned char*)(base + w.ks);
+  const int tiles = w.np / KT;
+  const dim3 grid(tiles, batch * heads);
+  const int q_tiles = (tokens + QT - 1) / QT;
+  const int total = batch * heads * q_tiles;
+#define FP8R_LAUNCH(DTV)                                                                                                \
+  {                                                                                                                     \
+    hipLaunchKernelGGL((quant_v_kernel<DTV>), grid, dim3(256), 0, st, (const unsigned short*)qkv, tokens, heads, w.np,  \
+                       amax, v8t);                                                                                      \
+    hipLaunchKernelGGL((attn_fp8_kernel<DTV, true>), dim3(total), dim3(256), 0, st, q8, k8, v8t, amax,                  \
+                       (unsigned short*)out, tokens, heads, w.np, q_tiles, total, qs, ks);                              \
+  }
+  if (dtype == VITTF_BF16) FP8R_LAUNCH(VITTF_BF16) else FP8R_LAUNCH(VITTF_FP16)
+#undef FP8R_LAUNCH
   return vittf_check_launch();
 }

@@ -155,8 +155,16 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
     // Default: q pre-scaled by log2(e)/8 in the qkv epilogue + the lazy-maximum attention kernel (168 VGPRs, 3 waves per
     // SIMD): 0.78 ms per launch in the pipeline against 0.87 ms for the online-maximum kernel (VITTF_ATTN_PRESCALED=0).
     static const int pre = [] { const char* e = getenv("VITTF_ATTN_PRESCALED"); return e ? atoi(e) : 1; }();
+    // fp8 attention at D = 768 (BASELINE configs[3]): q and k leave the qkv GEMM as fp8 rows with their own block scales, v
+    // with its absolute maxima collected on the way (vittf_gemm_qkv_fp8 + vittf_attention_fp8_rows) -- no absmax pass, a
+    // quantise pass over the v third only.  VITTF_FP8_ROWS=0: the per-(slice, head) scales of round 2 (three launches).
+    static const bool fp8_rows_env = [] { const char* e = getenv("VITTF_FP8_ROWS"); return !e || atoi(e) != 0; }();
+    const bool fp8_rows = fp8_rows_env && cfg->attention_fp8 && pre && !ln_fused && d >= 768 && d % 256 == 0;
     { ProfScope ps(VITTF_KERNEL_GEMM_QKV, stream);
-      if (ln_fused)
+      if (fp8_rows)
+        rc = vittf_gemm_qkv_fp8(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, tokens, cfg->heads, dt,
+                                base + lay.fp8, lay.fp8_bytes, stream);
+      else if (ln_fused)
         rc = vittf_ln_gemm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, cfg->ln_eps, qkv_w,
                            w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, dt,
                            stream);
@@ -165,7 +173,9 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
                         pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, 0, dt, stream); }
     if (rc) return rc;
     { ProfScope ps(VITTF_KERNEL_ATTENTION, stream);
-      if (cfg->attention_fp8 && pre)
+      if (fp8_rows)
+        rc = vittf_attention_fp8_rows(QKV, O, batch, tokens, cfg->heads, dt, base + lay.fp8, lay.fp8_bytes, stream);
+      else if (cfg->attention_fp8 && pre)
         rc = vittf_attention_fp8(QKV, O, batch, tokens, cfg->heads, dt, base + lay.fp8, lay.fp8_bytes, stream);
       else
         rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, pre, stream); }

@@ -64,13 +64,33 @@ __device__ __forceinline__ int p_img_off(int r, int kc) { return tile_off(r >> 1
 
 typedef __attribute__((ext_vector_type(4))) unsigned pu32x4_t;
 
+// The qkv projection with q and k leaving as fp8 (e4m3) rows with MX block scales -- one power-of-two (E8M0 byte) per row and
+// 32-wide block -- in the layout attention_fp8.hip reads ([slice][head][token][64] bytes in the instruction's block order,
+// [slice][head][token][2] scale bytes),
+// v as 16-bit values in `out` (the qkv buffer's v third) with its per-(slice, head) absolute maximum collected on the way
+// (internal epilogue id; entry point vittf_gemm_qkv_fp8 below).
+constexpr int PP_EPI_QKV_FP8 = 100;
+struct PpFp8Out {
+  unsigned char* q8; unsigned char* k8; unsigned char* qs; unsigned char* ks; unsigned* amax;
+  int np, heads, batch;
+};
+
+// power-of-two scale exponent for a block with absolute maximum amax: amax * 2^-e <= 448 (e4m3 maximum), e >= -20
+// (the rule of attention_fp8.hip's scale_exp)
+__device__ __forceinline__ int pp_scale_exp(float amax) {
+  if (!(amax > 0.f)) return 0;
+  int ex;
+  (void)frexpf(amax * (1.0f / 448.0f), &ex);
+  return ex < -20 ? -20 : ex;
+}
+
 struct Frags { s16x8_t a[4][2], w[2][2]; };      // [32-row block][k16 step]
 
 template <int DT, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W,
                                                          const float* __restrict__ bias, void* __restrict__ out, int64_t rows,
                                                          int n, int k, int tokens, int n_tiles, int total_tiles,
-                                                         unsigned out_bytes) {
+                                                         unsigned out_bytes, PpFp8Out f8) {
   __shared__ __attribute__((aligned(16))) char smem[PLDS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,6 +99,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
   const int G = gridDim.x;
   const int nk = k / PBK;                        // even, >= 24
   // buffer stores a thread leaves in flight per tile: 8 parts x 4 (fp32 read-modify-write) or x 2 (16 bytes of 16-bit values)
+  // (the fp8 qkv epilogue: 16 = its v tiles; its q / k tiles leave 32: the smaller number only waits a little earlier)
   constexpr int SPT = EPI == VITTF_EPI_BIAS_RESIDUAL ? 32 : 16;
 
   // ---- LDS-DMA: chunk q = i * 512 + tid of an image <- (row, k chunk) by the inverse of p_img_off; 2 + 2 pieces per wave ----
@@ -203,12 +224,21 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
     int64_t m0; int n0;
     tile_origin(c_vb, m0, n0);
     const bool last_tile = c_vb + G >= total_tiles;
+    // the accumulators start from the bias of their columns: 8 consecutive floats per (ni, g) at a wave-uniform address =
+    // scalar loads (lgkmcnt: no place in the in-order vector-memory queue behind the previous tile's stores), the lane
+    // half picks its four
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float* bq = bias + n0 + wc * 64 + i * 32 + 8 * g4;
+        const float4 lo = *reinterpret_cast<const float4*>(bq), hi = *reinterpret_cast<const float4*>(bq + 4);
+        const float4 sel = h ? hi : lo;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j][4 * g4 + 0] = sel.x; acc[i][j][4 * g4 + 1] = sel.y; acc[i][j][4 * g4 + 2] = sel.z; acc[i][j][4 * g4 + 3] = sel.w;
+        }
+      }
     stage(fx, fy, true, !first_tile);
     stage(fy, fx, true, !first_tile);
     for (int t = 2; t < nk - 2; t += 2) {
@@ -234,7 +264,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
       // The tile leaves in eight parts of 32 rows x 256 columns.  Writers (the four waves of the part's group) put their raw
       // fp32 accumulators into the staging area a row per lane (16-byte chunk index XOR row: conflict-free both ways); after
       // the barrier ALL eight waves pick the part up as 1 KB row segments -- a thread owns four columns of four rows -- add
-      // the bias, apply the epilogue's function and send the result off: 512-byte runs of 16-bit values, or the fp32
+      // apply the epilogue's function (the bias is already in: the accumulators started from it) and send the result off: 512-byte runs of 16-bit values, or the fp32
       // read-modify-write of the residual stream (x of a part is requested before the part is staged).  Always four buffer
       // stores per thread and part (rows past the end fall outside the descriptor): the counted waits of the next tile's
       // first stage know the number.
@@ -243,9 +273,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
       // residual: a thread owns 4 columns (one staged chunk) of 4 rows; 16-bit outputs: 8 columns (two chunks -> one 16-byte
       // store: the epilogue is bound by the NUMBER of store instructions) of 2 rows
       const int ch = RES ? (tid & 63) : 2 * (tid & 31);
-      const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + 4 * ch);
-      [[maybe_unused]] const float4 bw = RES ? bv : *reinterpret_cast<const float4*>(bias + n0 + 4 * ch + 4);
-      [[maybe_unused]] const float qs = (n0 + 4 * ch) < n / 3 ? 0.125f * 1.44269504088896340736f : 1.0f;
+      [[maybe_unused]] const float qs = (n0 + 4 * ch) < n / 3 ? 0.125f * 1.44269504088896340736f : 1.0f;   // (uniform per tile when 256 | n / 3)
+      [[maybe_unused]] float vmax_a = 0.f, vmax_b = 0.f;     // (fp8 qkv epilogue, v tiles) this thread's maxima: first / second slice of the tile
+      [[maybe_unused]] int64_t fb0 = 0;
+      if constexpr (EPI == PP_EPI_QKV_FP8) fb0 = m0 / tokens;
 #pragma unroll 1
       for (int sp = 0; sp < 8; ++sp) {
         const int pg = sp >> 2, pm = sp & 3;
@@ -280,13 +311,71 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
           }
         }
         PP_BARRIER();
-        if constexpr (RES) {
+        if constexpr (EPI == PP_EPI_QKV_FP8) {
+          // a thread owns 16 columns (four staged chunks) of ONE row of the part: 16 fp8 bytes = one 16-byte store.  A column
+          // tile lies inside ONE third (256 | n / 3): the whole tile is q, k or v.
+          const int rl = tid >> 4, c16 = tid & 15;
+          const int dm = n / 3, third = n0 / dm;
+          float v[16];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 dv = *reinterpret_cast<const float4*>(stg + rl * 1024 + (((4 * c16 + j) ^ rl) << 4));
+            v[4 * j + 0] = dv.x * qs; v[4 * j + 1] = dv.y * qs; v[4 * j + 2] = dv.z * qs; v[4 * j + 3] = dv.w * qs;
+          }
+          float mx = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(v[e]));
+          const int64_t m = row0 + rl;
+          int64_t b = fb0;                                       // (slice of the row: at most one boundary inside a tile ...
+          if (tokens < PBM) b = m / tokens;                      //  ... unless the slices are tiny)
+          else if (m >= (fb0 + 1) * (int64_t)tokens) b = fb0 + 1;
+          const int tok = (int)(m - b * tokens);
+          if (third < 2) {
+            // this row's 32-wide block = the 16 + 16 columns of two neighbouring lanes: block maximum -> E8M0 scale -> e4m3 bytes
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            const int ex = pp_scale_exp(mx);
+            const float inv = ldexpf(1.0f, -ex);
+            pu32x4_t pk8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * j] * inv, v[4 * j + 1] * inv, 0, false);
+              w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * j + 2] * inv, v[4 * j + 3] * inv, w0, true);
+              pk8[j] = (unsigned)w0;
+            }
+            const int col = (n0 - third * dm) + 16 * c16;                   // column inside the third: head 64 * hd + dim
+            const int hd = col >> 6, dim = col & 63;
+            // position of dim inside the 64-byte row: the matrix instruction's MX block b of a row is bytes 16 b .. 16 b + 15 of
+            // BOTH lane halves (k = 32 (byte >> 4) + 16 (lane >> 5) + (byte & 15): tools/micro/mfma_f8_scale_probe2), and the
+            // attention kernel's lane half hh reads bytes 32 hh .. 32 hh + 31: a row is stored as [d 0-15 | d 32-47 | d 16-31 | d 48-63]
+            const int pos = ((dim >> 4) & 1) * 32 + (dim >> 5) * 16;
+            const int64_t rowi = (b * f8.heads + hd) * f8.np + tok;
+            const bool ok = m < rows;
+            const int64_t total8 = (int64_t)f8.batch * f8.heads * f8.np;
+            const auto r8 = __builtin_amdgcn_make_buffer_rsrc(third == 0 ? f8.q8 : f8.k8, 0, (int)(unsigned)(total8 * 64), 0x00020000);
+            const auto rsc = __builtin_amdgcn_make_buffer_rsrc(third == 0 ? f8.qs : f8.ks, 0, (int)(unsigned)(total8 * 2), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(pk8, r8, ok ? (int)(unsigned)(rowi * 64 + pos) : -1, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(127 + ex), rsc, (ok && (c16 & 1) == 0) ? (int)(unsigned)(rowi * 2 + (dim >> 5)) : -1, 0, 0);
+          } else {
+            // v: 16-bit values into the qkv buffer's v third; its absolute maximum per (slice, head) on the way out
+            if (tokens < PBM) {          // (tiny slices: a tile holds more than two of them -- one atomic per thread and row)
+              const int hd = ((n0 - 2 * dm) + 16 * c16) >> 6;
+              if (m < rows && mx > 0.f) atomicMax(f8.amax + (b * f8.heads + hd) * 3 + 2, __float_as_uint(mx));
+            } else if (m < rows) {
+              if (b == fb0) vmax_a = fmaxf(vmax_a, mx); else vmax_b = fmaxf(vmax_b, mx);
+            }
+            pu32x4_t p0, p1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { p0[e] = pack2_h16<DT>(v[2 * e], v[2 * e + 1]); p1[e] = pack2_h16<DT>(v[8 + 2 * e], v[8 + 2 * e + 1]); }
+            __builtin_amdgcn_raw_buffer_store_b128(p0, rs, (rl * n + 16 * c16) * 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, rs, (rl * n + 16 * c16) * 2 + 16, 0, 0);
+          }
+        } else if constexpr (RES) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int rl = i * 8 + (tid >> 6);
             const float4 d = *reinterpret_cast<const float4*>(stg + rl * 1024 + ((ch ^ rl) << 4));
             float4 x = __builtin_bit_cast(float4, xv[i]);
-            x.x += d.x + bv.x; x.y += d.y + bv.y; x.z += d.z + bv.z; x.w += d.w + bv.w;
+            x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4_t, x), rs, (rl * n + 4 * ch) * 4, 0, 0);
           }
         } else {
@@ -295,7 +384,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
             const int rl = i * 16 + (tid >> 5);
             const float4 d0 = *reinterpret_cast<const float4*>(stg + rl * 1024 + ((ch ^ rl) << 4));
             const float4 d1 = *reinterpret_cast<const float4*>(stg + rl * 1024 + (((ch + 1) ^ rl) << 4));
-            float v[8] = {d0.x + bv.x, d0.y + bv.y, d0.z + bv.z, d0.w + bv.w, d1.x + bw.x, d1.y + bw.y, d1.z + bw.z, d1.w + bw.w};
+            float v[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               if constexpr (EPI == VITTF_EPI_BIAS_GELU) v[e] = gelu_poly(v[e]);
@@ -320,6 +409,22 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
         }
         PP_BARRIER();
       }
+      if constexpr (EPI == PP_EPI_QKV_FP8) {
+        const int dm = n / 3;
+        if (n0 / dm == 2) {
+          // the 4 lanes that share a head (16 columns each), then the wave's four rows: one atomic per head, slice and wave
+#pragma unroll
+          for (int off = 1; off <= 2; off <<= 1) { vmax_a = fmaxf(vmax_a, __shfl_xor(vmax_a, off)); vmax_b = fmaxf(vmax_b, __shfl_xor(vmax_b, off)); }
+#pragma unroll
+          for (int off = 16; off <= 32; off <<= 1) { vmax_a = fmaxf(vmax_a, __shfl_xor(vmax_a, off)); vmax_b = fmaxf(vmax_b, __shfl_xor(vmax_b, off)); }
+          if ((lane & 51) == 0) {                // lanes 0, 4, 8, 12
+            const int hd = ((n0 - 2 * dm) >> 6) + (lane >> 2);
+            const int64_t b0 = m0 / tokens;
+            if (vmax_a > 0.f) atomicMax(f8.amax + (b0 * f8.heads + hd) * 3 + 2, __float_as_uint(vmax_a));
+            if (vmax_b > 0.f && b0 + 1 < f8.batch) atomicMax(f8.amax + ((b0 + 1) * f8.heads + hd) * 3 + 2, __float_as_uint(vmax_b));
+          }
+        }
+      }
     }
     if (last_tile) break;
     c_vb += G;
@@ -328,7 +433,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
 
 template <int DT>
 int launch_pp(const void* a, const void* w, const float* bias, void* out, int64_t rows, int n, int k, int epi, int tokens,
-              hipStream_t st) {
+              hipStream_t st, PpFp8Out f8 = PpFp8Out{}) {
   const int64_t m_tiles = (rows + PBM - 1) / PBM;
   const int n_tiles = n / PBN;
   const int64_t total64 = m_tiles * n_tiles;
@@ -349,7 +454,7 @@ int launch_pp(const void* a, const void* w, const float* bias, void* out, int64_
 #define VITTF_PP_CASE(E)                                                                                              \
   case E:                                                                                                             \
     hipLaunchKernelGGL((gemm_pp_kernel<DT, E>), dim3(grid), dim3(512), 0, st, A, Wp, bias, out, rows, n, k, tokens,   \
-                       n_tiles, total, out_bytes);                                                                    \
+                       n_tiles, total, out_bytes, f8);                                                                \
     break;
   switch (epi) {
     VITTF_PP_CASE(VITTF_EPI_BIAS)
@@ -357,6 +462,7 @@ int launch_pp(const void* a, const void* w, const float* bias, void* out, int64_
     VITTF_PP_CASE(VITTF_EPI_BIAS_RESIDUAL)
     VITTF_PP_CASE(VITTF_EPI_KFEAT)
     VITTF_PP_CASE(VITTF_EPI_BIAS_QKV)
+    VITTF_PP_CASE(PP_EPI_QKV_FP8)
     default: return VITTF_ERR_INVALID_ARG;
   }
 #undef VITTF_PP_CASE
@@ -383,3 +489,32 @@ int vittf_gemm_pp(const void* a, const void* w, const float* bias, void* out, in
   if (dtype == VITTF_FP16) return launch_pp<VITTF_FP16>(a, w, bias, out, rows, n, k, epilogue, tokens, st);
   return VITTF_ERR_INVALID_ARG;
 }
+
+#ifndef PP_STANDALONE
+void vittf_fp8_ws_pointers(void* ws, int32_t batch, int32_t tokens, int32_t heads, unsigned** amax, unsigned char** q8,
+                           unsigned char** k8, unsigned char** qs, unsigned char** ks, int32_t* np);   // attention_fp8.hip
+
+// Attention.qkv with fp8 outputs for vittf_attention_fp8_rows: see include/vittf.h
+extern "C" int vittf_gemm_qkv_fp8(const void* a, const void* w, const float* bias, void* qkv_out, int64_t rows, int32_t n,
+                                  int32_t k, int32_t tokens, int32_t heads, int32_t dtype, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  if (!a || !w || !bias || !qkv_out || !ws || rows <= 0 || tokens <= 0 || heads <= 0) return VITTF_ERR_INVALID_ARG;
+  if (n != 3 * heads * 64 || (n / 3) % PBN != 0 || k < 768 || k % (2 * PBK) != 0) return VITTF_ERR_INVALID_ARG;
+  if (rows % tokens != 0 || rows / tokens > 0x7fffffff) return VITTF_ERR_INVALID_ARG;
+  if ((int64_t)k * 2 * PBM > 0x7fffffff || (int64_t)n * 4 * 64 > 0x7fffffff) return VITTF_ERR_INVALID_ARG;
+  if ((((uintptr_t)a | (uintptr_t)w | (uintptr_t)qkv_out) & 15) != 0 || ((uintptr_t)ws & 255) != 0) return VITTF_ERR_INVALID_ARG;
+  if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
+  const int batch = (int)(rows / tokens);
+  if (ws_bytes < vittf_attention_fp8_workspace_bytes(batch, tokens, heads)) return VITTF_ERR_WORKSPACE;
+  PpFp8Out f8;
+  int np = 0;
+  vittf_fp8_ws_pointers(ws, batch, tokens, heads, &f8.amax, &f8.q8, &f8.k8, &f8.qs, &f8.ks, &np);
+  f8.np = np; f8.heads = heads; f8.batch = batch;
+  if ((int64_t)batch * heads * np * 64 > 0xfffffff0ll) return VITTF_ERR_INVALID_ARG;       // 32-bit byte offsets into q8 / k8
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(f8.amax, 0, (size_t)batch * heads * 3 * 4, st) != hipSuccess) return VITTF_ERR_LAUNCH;
+  vittf_note_kernel(VITTF_KERNEL_GEMM_QKV, "gemm_pp_kernel<qkv -> fp8 q, k + row scales>");
+  if (dtype == VITTF_BF16) return launch_pp<VITTF_BF16>(a, w, bias, qkv_out, rows, n, k, PP_EPI_QKV_FP8, tokens, st, f8);
+  return launch_pp<VITTF_FP16>(a, w, bias, qkv_out, rows, n, k, PP_EPI_QKV_FP8, tokens, st, f8);
+}
+#endif
