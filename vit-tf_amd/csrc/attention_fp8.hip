@@ -359,19 +359,7 @@ __global__ __launch_bounds__(256, 3) void attn_fp8_kernel(const unsigned char* _
     l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
   const float inv = P_HEADROOM / l_tot;
-  if (qrow < tokens) {
-    unsigned short* orow = out + ((int64_t)b * tokens + qrow) * dmodel + hd * 64 + 4 * hh;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      uint2 pk;
-      pk.x = pack2_h16<DT>(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv);
-      pk.y = pack2_h16<DT>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-      *reinterpret_cast<uint2*>(orow + 8 * g) = pk;
-      pk.x = pack2_h16<DT>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv);
-      pk.y = pack2_h16<DT>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-      *reinterpret_cast<uint2*>(orow + 32 + 8 * g) = pk;
-    }
-  }
+  if (qrow < tokens) store_o_row<DT>(out + ((int64_t)b * tokens + qrow) * dmodel + hd * 64, hh, o0, o1, inv);
 }
 
 struct Fp8Ws { size_t amax, q8, k8, v8t, qs, ks, total; int np; };

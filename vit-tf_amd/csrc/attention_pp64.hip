@@ -400,24 +400,13 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(const unsigned short*
     else       B.o0 = mfma32<DT>(vf.v[j], pb[j >> 1], B.o0);
   }
 
-  // ---- normalise and store: lane owns query rows qrow_a / qrow_b, columns 32 dvt + 8 g + 4 h + {0..3} ----
+  // ---- normalise and store: lane owns query rows qrow_a / qrow_b, columns 32 dvt + 8 g + 4 h + {0..3}
+  //      (store_o_row pairs them into 16-byte runs) ----
   auto store = [&](const Blk& X, int qrow) {
     const unsigned lb = __float_as_uint(X.l_run);
     const auto sw = __builtin_amdgcn_permlane32_swap(lb, lb, false, false);
     const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
-    if (qrow < tokens) {
-      unsigned short* orow = out + ((int64_t)bi * tokens + qrow) * dmodel + hd * 64 + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 pk;
-        pk.x = pack2_h16<DT>(X.o0[4 * g + 0] * inv, X.o0[4 * g + 1] * inv);
-        pk.y = pack2_h16<DT>(X.o0[4 * g + 2] * inv, X.o0[4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(orow + 8 * g) = pk;
-        pk.x = pack2_h16<DT>(X.o1[4 * g + 0] * inv, X.o1[4 * g + 1] * inv);
-        pk.y = pack2_h16<DT>(X.o1[4 * g + 2] * inv, X.o1[4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(orow + 32 + 8 * g) = pk;
-      }
-    }
+    if (qrow < tokens) store_o_row<DT>(out + ((int64_t)bi * tokens + qrow) * dmodel + hd * 64, h, X.o0, X.o1, inv);
   };
   store(A, qrow_a);
   store(B, qrow_b);
