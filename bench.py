@@ -112,6 +112,7 @@ def query_voxels(label, n=N_QUERIES):
 KERNEL_SOURCES = {     # what a kernel's code object is built from: its source, the shared headers and the Makefile's flags
     'attention': ('attention_pp64.hip', 'attn_common.h', 'vittf_common.h', 'Makefile'),
     'similarity': ('sim_mfma.hip', 'similarity.hip', 'vittf_common.h', 'Makefile'),
+    'block_tail': ('mlp.hip', 'vittf_common.h', 'Makefile'),
 }
 
 
@@ -414,12 +415,18 @@ def main():
     roofline_tail = None
     if prof['mlp'][1] > 0 and prof['mlp'][0] > 0:
         t_ms, t_n = prof['mlp']
+        t_rows = (args.engine_batch if my_slices >= args.engine_batch else my_slices) * n_tokens
         t_ach = flops['mlp'] / (t_ms * 1e-3) / 1e12
         tpeak = PEAK_TFLOPS[args.dtype]
         roofline_tail = {'bound': 'mfma', 'achieved': round(t_ach, 2), 'peak': tpeak, 'unit': 'TFLOP/s', 'frac': round(t_ach / tpeak, 4),
-                         'traffic': None, 'kernel': kernels['mlp'], 'launches': int(t_n), 'avg_launch_ms': round(t_ms / t_n, 4),
+                         'traffic': pmc_traffic('block_tail', args.engine_batch if my_slices >= args.engine_batch else my_slices,
+                                                tokens=n_tokens, features=dim),
+                         'kernel': kernels['mlp'], 'launches': int(t_n), 'avg_launch_ms': round(t_ms / t_n, 4),
                          'flop_per_launch': flops['mlp'] / t_n,
-                         'note': 'events around its launches in one extra untimed step; PMC of the kernel: profiles/r03d_block_tail_pmc.txt'}
+                         'algorithmic_bytes_per_launch': int(t_rows * (dim * 2 + dim * 4 * 2 + dim * 2)),
+                         'note': 'events around its launches in one extra untimed step; algorithmic bytes per token row: attention output in '
+                                 '(2 D) + fp32 residual in and out (8 D) + 16-bit LayerNorm output (2 D); the 2.65 MB of weights every '
+                                 'workgroup re-reads come from L2 / the Infinity Cache; traffic: profiles/pmc_block_tail.json'}
 
     if rank == 0:
         out = {

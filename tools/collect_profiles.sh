@@ -13,6 +13,7 @@ f=$(ls -t $O/prof512/runc/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] 
 [ -f $O/pmc_tail.log ] && cp $O/pmc_tail.log $P/${tag}_block_tail_pmc.txt
 [ -f $O/pmc_attention.json ] && cp $O/pmc_attention.json $P/pmc_attention.json
 [ -f $O/pmc_similarity.json ] && cp $O/pmc_similarity.json $P/pmc_similarity.json
+[ -f $O/pmc_block_tail.json ] && cp $O/pmc_block_tail.json $P/pmc_block_tail.json
 for t in kernels pipeline fullsize; do [ -f $O/test_$t.log ] && tail -n 40 $O/test_$t.log > $P/${tag}_test_$t.tail.txt; done
 [ -f $O/test_all.log ] && tail -n 60 $O/test_all.log > $P/${tag}_test_all_one_process.tail.txt
 [ -f $O/bench512_fos128.log ] && last_json $O/bench512_fos128.log > $P/${tag}_bench512_fos128.json

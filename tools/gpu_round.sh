@@ -42,7 +42,8 @@ for s in "$@"; do
               python tools/pmc_json.py similarity $OUT/pmc_sim.log sim_mfma_few $OUT/pmc_similarity.json batch=16 nvox=262144 features=384 kernel=sim_mfma_few_kernel > /dev/null ;;
     pmctail)  export BATCH=256 DT=fp16
               step pmc_tail 900 bash tools/pmc_attn.sh tail
-              unset BATCH ;;
+              unset BATCH
+              python tools/pmc_json.py block_tail $OUT/pmc_tail.log mlp_kernel $OUT/pmc_block_tail.json batch=256 tokens=4097 features=384 > /dev/null ;;
     fp8)      step test_fp8 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -q -m gpu -s -p no:cacheprovider -k "fp8 or vitb8" ;;
     benchb)   for a in 16bit fp8; do VITTF_BENCH_OVERLAP=0 step benchb_$a 600 python bench.py --arch vitb8 --workload 64 --attention $a --cpu-slices 0 --steps 2; done ;;
     benchb512) for a in 16bit fp8; do VITTF_BENCH_OVERLAP=0 step benchb512_$a 600 python bench.py --arch vitb8 --attention $a --cpu-slices 0 --steps 2; done ;;

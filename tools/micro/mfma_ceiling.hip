@@ -140,6 +140,16 @@ __global__ __launch_bounds__(256) void mfma_loop(const _Float16* __restrict__ sr
                      : "v"(x[0]), "v"(x[1]), "v"(0xcb00cb00u), "v"(0x66006600u), "v"(0x2b1b2b1bu), "v"(0x33b033b0u), "v"(0x398c398cu),
                        "v"(0x3c003c00u), "v"(0x04000400u), "v"(0u));
         pk = p_;
+      } else if constexpr (FILL == 14) { // row sums on the PACKED pair: 2 v_exp + 1 v_cvt_pk + 1 v_pk_add_f16 (7 of 8 gaps; fp32 once per phase)
+        asm volatile("v_exp_f32 %0, %4\n\tv_exp_f32 %1, %5\n\tv_cvt_pk_f16_f32 %2, %6, %7\n\tv_pk_add_f16 %3, %3, %8"
+                     : "=&v"(ea0), "=&v"(ea1), "=&v"(pk), "+v"(pk2) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1), "v"(pkprev));
+        pkprev = pk;
+      } else if constexpr (FILL == 15) { // no row sums at all (the floor of any scheme that moves them): 2 v_exp + 1 v_cvt_pk
+        asm volatile("v_exp_f32 %0, %3\n\tv_exp_f32 %1, %4\n\tv_cvt_pk_f16_f32 %2, %5, %6"
+                     : "=&v"(ea0), "=&v"(ea1), "=&v"(pk) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1));
+      } else if constexpr (FILL == 16) { // 2 v_exp + 1 v_cvt_pk + 1 v_add_f32 (e.g. one fp32 add of a pre-added pair)
+        asm volatile("v_exp_f32 %0, %4\n\tv_exp_f32 %1, %5\n\tv_cvt_pk_f16_f32 %2, %6, %7\n\tv_add_f32 %3, %3, %6"
+                     : "=&v"(ea0), "=&v"(ea1), "=&v"(pk), "+v"(s0) : "v"(x[0]), "v"(x[1]), "v"(eb0), "v"(eb1));
       } else if constexpr (FILL == 5) { // three plain VALU (the mix without its exps)
         asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_cvt_pk_f16_f32 %2, %3, %4"
                      : "+v"(s0), "+v"(s1), "=&v"(pk) : "v"(eb0), "v"(eb1));
@@ -216,6 +226,10 @@ int main() {
     run<4, 8>("MFMA + 2 v_exp + 1 v_cvt_pk + 1/2 mfma_4x4x4 (row sums)", w, src, out, st);
     run<4, 9>("MFMA + 2 v_exp + 1 v_cvt_pk + 1 v_dot2_f32_f16", w, src, out, st);
     run<4, 10>("MFMA + 2 v_exp + 1 v_cvt_pk + 1 v_dot2c_f32_f16", w, src, out, st);
+    run<4, 14>("MFMA + 2 v_exp + 1 v_cvt_pk + 1 v_pk_add_f16", w, src, out, st);
+    run<4, 15>("MFMA + 2 v_exp + 1 v_cvt_pk (no row sums)", w, src, out, st);
+    run<4, 16>("MFMA + 2 v_exp + 1 v_cvt_pk + 1 v_add_f32", w, src, out, st);
+    run<4, 14, 0>("no MFMA: 2 v_exp + 1 v_cvt_pk + 1 v_pk_add_f16", w, src, out, st);
     run<4, 11>("MFMA + packed-fp16 polynomial exp2 x 2 (11 VALU, no v_exp)", w, src, out, st);
     run<4, 12>("MFMA + v_exp mix / packed polynomial in alternate gaps", w, src, out, st);
     run<4, 13>("MFMA + packed polynomial exp2 x 2 without row sums (10)", w, src, out, st);
