@@ -544,35 +544,71 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
       for (int ot = 0; ot < XE; ++ot) x_request(ot);
     }
     float s = 0.f;
-#pragma unroll
-    for (int ot = 0; ot < D / 32; ++ot) {
-      if constexpr (!TAIL) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(lds_w4_ptr)(stg_rd_e + i * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[ot % XE][i]);
-        if (ot + XE < D / 32) x_request(ot + XE);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = cst4(C_B2 + 32 * ot + 8 * g);
-        f32x4_t v;
-        v[0] = xacc[ot][4 * g + 0] + bv.x; v[1] = xacc[ot][4 * g + 1] + bv.y;
-        v[2] = xacc[ot][4 * g + 2] + bv.z; v[3] = xacc[ot][4 * g + 3] + bv.w;
-        if constexpr (!TAIL) {
-          const f32x4_t xv = *(lds_f4_ptr)(stg_wr_e + 32 * g);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = xv[e] + v[e];
+    if constexpr (TAIL) {
+      // The constants of an output tile are requested one tile ahead and the read-back of the staging rows as ONE group: left to
+      // itself hipcc issues every LDS read with its own lgkmcnt(0) wait in front of the one instruction that uses it (8 exposed
+      // round trips per output tile: 1.3 k cycles of the single wave a SIMD has).  The fences only delimit the groups.
+      float4 bvq[2][4];
+  #pragma unroll
+      for (int g = 0; g < 4; ++g) bvq[0][g] = cst4(C_B2 + 8 * g);
+  #pragma unroll
+      for (int ot = 0; ot < D / 32; ++ot) {
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = bvq[ot & 1][g];
+          f32x4_t v;
+          v[0] = xacc[ot][4 * g + 0] + bv.x; v[1] = xacc[ot][4 * g + 1] + bv.y;
+          v[2] = xacc[ot][4 * g + 2] + bv.z; v[3] = xacc[ot][4 * g + 3] + bv.w;
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) xacc[ot][4 * g + e] = v[e];
+          *(lds_w4_ptr)(stg_wr_e + 32 * g) = v;
+          s += (v[0] + v[1]) + (v[2] + v[3]);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xacc[ot][4 * g + e] = v[e];
-        *(lds_w4_ptr)(stg_wr_e + 32 * g) = v;
-        s += (v[0] + v[1]) + (v[2] + v[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4_t rb[4];
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = *(lds_f4_ptr)(stg_rd_e + i * 8 * STG_ROW);
+        if (ot + 1 < D / 32) {
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) bvq[(ot + 1) & 1][g] = cst4(C_B2 + 32 * (ot + 1) + 8 * g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, rb[i]), io.x, xo_e + ot * 128, i * 8 * (D * 4), RT_AUX);
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4_t v = *(lds_f4_ptr)(stg_rd_e + i * 8 * STG_ROW);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.x, xo_e + ot * 128, i * 8 * (D * 4), RT_AUX);
+    } else {      // (the MLP alone: its residual tiles already take the registers the groups would need -- 80 spills)
+  #pragma unroll
+      for (int ot = 0; ot < D / 32; ++ot) {
+        if constexpr (!TAIL) {
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) *(lds_w4_ptr)(stg_rd_e + i * 8 * STG_ROW) = __builtin_bit_cast(f32x4_t, xi[ot % XE][i]);
+          if (ot + XE < D / 32) x_request(ot + XE);
+        }
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = cst4(C_B2 + 32 * ot + 8 * g);
+          f32x4_t v;
+          v[0] = xacc[ot][4 * g + 0] + bv.x; v[1] = xacc[ot][4 * g + 1] + bv.y;
+          v[2] = xacc[ot][4 * g + 2] + bv.z; v[3] = xacc[ot][4 * g + 3] + bv.w;
+          if constexpr (!TAIL) {
+            const f32x4_t xv = *(lds_f4_ptr)(stg_wr_e + 32 * g);
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = xv[e] + v[e];
+          }
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) xacc[ot][4 * g + e] = v[e];
+          *(lds_w4_ptr)(stg_wr_e + 32 * g) = v;
+          s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4_t v = *(lds_f4_ptr)(stg_rd_e + i * 8 * STG_ROW);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.x, xo_e + ot * 128, i * 8 * (D * 4), RT_AUX);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
     MLP_STAMP(5);
     if constexpr (!TAIL) request_next_fragments();
@@ -597,28 +633,65 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const unsigned short* __res
       const float rstd = 1.0f / sqrtf(q / (float)D + ln_eps);
       float mean_p = mean;
       asm volatile("" : "+v"(mean_p));
-#pragma unroll
-      for (int op = 0; op < D / 64; ++op) {            // two output tiles = 64 columns = 128 bytes of a 16-bit row
-#pragma unroll
-        for (int o2 = 0; o2 < 2; ++o2) {
-          const int ot = 2 * op + o2;
-#pragma unroll
+      if constexpr (TAIL) {
+        // gamma / beta of an output tile one tile ahead, the read-back as one group (as above)
+        float4 gq1[2][4], bq1[2][4];
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) { gq1[0][g] = cst4(C_G1 + 8 * g); bq1[0][g] = cst4(C_E1 + 8 * g); }
+  #pragma unroll
+        for (int ot = 0; ot < D / 32; ++ot) {            // two output tiles = 64 columns = 128 bytes of a 16-bit row
+          const int op = ot >> 1, o2 = ot & 1;
+  #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int col = 32 * ot + 8 * g;
-            const float4 gg = cst4(C_G1 + col);
-            const float4 bb = cst4(C_E1 + col);
+            const float4 gg = gq1[ot & 1][g];
+            const float4 bb = bq1[ot & 1][g];
             u32x2_t pk;
             pk[0] = pack2_h16<DT>((xacc[ot][4 * g + 0] - mean_p) * rstd * gg.x + bb.x, (xacc[ot][4 * g + 1] - mean_p) * rstd * gg.y + bb.y);
             pk[1] = pack2_h16<DT>((xacc[ot][4 * g + 2] - mean_p) * rstd * gg.z + bb.z, (xacc[ot][4 * g + 3] - mean_p) * rstd * gg.w + bb.w);
             *(lds_w2_ptr)(stg_wh + 64 * o2 + 16 * g) = pk;
           }
+          __builtin_amdgcn_sched_barrier(0);
+          [[maybe_unused]] f32x4_t rb[4];
+          if (o2) {
+  #pragma unroll
+            for (int i = 0; i < 4; ++i) rb[i] = *(lds_f4_ptr)(stg_rd_e + i * 8 * STG_ROW);
+          }
+          if (ot + 1 < D / 32) {
+  #pragma unroll
+            for (int g = 0; g < 4; ++g) { gq1[(ot + 1) & 1][g] = cst4(C_G1 + 32 * (ot + 1) + 8 * g); bq1[(ot + 1) & 1][g] = cst4(C_E1 + 32 * (ot + 1) + 8 * g); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (o2) {
+  #pragma unroll
+            for (int i = 0; i < 4; ++i)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, rb[i]), io.h_out, ho + op * 128, i * 8 * (D * 2), RT_AUX);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x4_t v = *(lds_f4_ptr)(stg_rd_e + i * 8 * STG_ROW);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.h_out, ho + op * 128, i * 8 * (D * 2), RT_AUX);
+      } else {
+  #pragma unroll
+        for (int op = 0; op < D / 64; ++op) {            // two output tiles = 64 columns = 128 bytes of a 16-bit row
+  #pragma unroll
+          for (int o2 = 0; o2 < 2; ++o2) {
+            const int ot = 2 * op + o2;
+  #pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int col = 32 * ot + 8 * g;
+              const float4 gg = cst4(C_G1 + col);
+              const float4 bb = cst4(C_E1 + col);
+              u32x2_t pk;
+              pk[0] = pack2_h16<DT>((xacc[ot][4 * g + 0] - mean_p) * rstd * gg.x + bb.x, (xacc[ot][4 * g + 1] - mean_p) * rstd * gg.y + bb.y);
+              pk[1] = pack2_h16<DT>((xacc[ot][4 * g + 2] - mean_p) * rstd * gg.z + bb.z, (xacc[ot][4 * g + 3] - mean_p) * rstd * gg.w + bb.w);
+              *(lds_w2_ptr)(stg_wh + 64 * o2 + 16 * g) = pk;
+            }
+          }
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4_t v = *(lds_f4_ptr)(stg_rd_e + i * 8 * STG_ROW);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), io.h_out, ho + op * 128, i * 8 * (D * 2), RT_AUX);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     MLP_STAMP(7);
