@@ -119,22 +119,23 @@ __device__ __forceinline__ void lds_dma16_keep(i32x4_t rsrc, unsigned lds_addr, 
 }
 
 // the exact-erf GELU of vittf_common.h (gelu_poly: the same operations in the same order, so the same bits) cut into three
-// pieces of at most 16 issue cycles, one per MFMA gap: beside an MFMA a one-wave SIMD hides about 24 cycles of other work
-struct Gelu3 { float z, p; };
+// pieces of at most 12 issue cycles, one per MFMA gap: beside an MFMA a one-wave SIMD hides about 24 cycles of other work
+struct Gelu3 { float x, p; };           // (x: ONE copy of the value out of the accumulator registers, used by all three pieces)
 __device__ __forceinline__ void gelu_a(Gelu3& s, float x) {
-  s.z = fabsf(x) * 0.70710678118654752f;
-  s.p = fmaf(-0.002965539f, s.z, 0.0296764448f);
-  s.p = fmaf(s.p, s.z, -0.148780614f);
-  s.p = fmaf(s.p, s.z, -0.918451846f);
-  asm volatile("" : "+v"(s.z), "+v"(s.p));         // pinned to this gap
+  s.x = x;
+  asm volatile("" : "+v"(s.x));
+  s.p = fmaf(-0.000524238159f, fabsf(s.x), 0.00741911121f);
+  s.p = fmaf(s.p, fabsf(s.x), -0.0526018888f);
+  s.p = fmaf(s.p, fabsf(s.x), -0.459225923f);
+  asm volatile("" : "+v"(s.x), "+v"(s.p));         // pinned to this gap
 }
 __device__ __forceinline__ void gelu_b(Gelu3& s) {
-  s.p = fmaf(s.p, s.z, -1.6278975f);
-  s.p = __builtin_amdgcn_exp2f(fmaf(s.p, s.z, -1.0f));
+  s.p = fmaf(s.p, fabsf(s.x), -1.15109742f);
+  s.p = __builtin_amdgcn_exp2f(fmaf(s.p, fabsf(s.x), -1.0f));
   asm volatile("" : "+v"(s.p));
 }
-__device__ __forceinline__ float gelu_c(const Gelu3& s, float x) {
-  float v = fmaf(-fabsf(x), s.p, fmaxf(x, 0.f));
+__device__ __forceinline__ float gelu_c(const Gelu3& s) {
+  float v = fmaf(-fabsf(s.x), s.p, fmaxf(s.x, 0.f));
   asm volatile("" : "+v"(v));
   return v;
 }
@@ -243,7 +244,7 @@ __device__ __forceinline__ void mlp_unit(Stream& st, unsigned (&base)[4], s16x8_
       } else if (j % 3 == 1) {
         gelu_b(gs);
       } else {
-        const float v = gelu_c(gs, gprev[r]);
+        const float v = gelu_c(gs);
         if (r & 1) {
           const unsigned w = pack2_h16<DT>(vprev, v);
           if (GH == 1) pk0[(r & 7) >> 1] = w; else pk1[(r & 7) >> 1] = w;

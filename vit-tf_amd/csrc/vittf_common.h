@@ -86,16 +86,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // exact-erf GELU  x Phi(x) = x - 0.5 x erfc(|x| / sqrt 2)  (x >= 0),  0.5 x erfc(|x| / sqrt 2)  (x < 0), with
 // erfc(z) = 2^-Q(z), Q a degree-5 polynomial without constant term (weighted minimax fit on [0, 4.2], monotone
 // beyond): |gelu error| <= 1.4e-6 absolute over all x (fit + check: tools/fit_gelu.py), far below the 16-bit
-// rounding of the result.  One v_exp_f32 and no reciprocal: 44 issue cycles per wave against 68 for the
+// rounding of the result.  One v_exp_f32 and no reciprocal: 40 issue cycles per wave against 68 for the
 // Abramowitz-Stegun 7.1.26 form (the epilogue of fc1 is VALU-bound: 201 M activations per launch).
 __device__ __forceinline__ float gelu_poly(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  float p = fmaf(-0.002965539f, z, 0.0296764448f);
-  p = fmaf(p, z, -0.148780614f);
-  p = fmaf(p, z, -0.918451846f);
-  p = fmaf(p, z, -1.6278975f);
-  const float e = __builtin_amdgcn_exp2f(fmaf(p, z, -1.0f));   // 0.5 erfc(z)
-  return fmaf(-fabsf(x), e, fmaxf(x, 0.f));                    // max(x, 0) - |x| 0.5 erfc(|x| / sqrt 2): both signs, 9 VALU
+  // Q in a = |x| itself: the 1 / sqrt 2 of z = a / sqrt 2 is folded into the coefficients (c_k 2^(-k/2), rounded once from the
+  // z form's: -1.6278975, -0.918451846, -0.148780614, 0.0296764448, -0.002965539) -- one multiply less per value, the same
+  // 1.26e-6 maximum error, within 2.4e-7 of the z form everywhere (7e-5 of all inputs round to another fp16 value)
+  float p = fmaf(-0.000524238159f, fabsf(x), 0.00741911121f);
+  p = fmaf(p, fabsf(x), -0.0526018888f);
+  p = fmaf(p, fabsf(x), -0.459225923f);
+  p = fmaf(p, fabsf(x), -1.15109742f);
+  const float e = __builtin_amdgcn_exp2f(fmaf(p, fabsf(x), -1.0f));   // 0.5 erfc(|x| / sqrt 2)
+  return fmaf(-fabsf(x), e, fmaxf(x, 0.f));                    // max(x, 0) - |x| 0.5 erfc(|x| / sqrt 2): both signs, 8 VALU
 }
 
 // sqrtf for NORMAL positive x, correctly rounded: v_sqrt_f32 (1 ulp) + the library's own correction step (try the two
