@@ -204,9 +204,11 @@ def save_features(qkv, cache_path):
 
 
 def _init_distributed():
-    """One process per GPU under torchrun (RANK/LOCAL_RANK/WORLD_SIZE); single process otherwise."""
+    """One process per GPU under torchrun (RANK/LOCAL_RANK/WORLD_SIZE); single process otherwise.  VITTF_DIST_FORCE=1 opens
+    the process group even for ONE rank (RANK / WORLD_SIZE / MASTER_* from the environment as usual), so that the slab
+    exchange -- in-place all_gather_into_tensor on RCCL, async, waited for in finish_exchanges -- runs on a one-GPU box."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if world <= 1 and not vt.extract.DIST_FORCE:
         return 0, 1
     local = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -228,13 +230,14 @@ def _agree_on_output_path(args, rank, world):
             cache_path = handle_output_path(args)
         except SystemExit as e:
             code = int(e.code) if isinstance(e.code, int) else 1
-    if world > 1:
+    grouped = world > 1 or torch.distributed.is_initialized()       # (a forced one-rank group takes the same calls)
+    if grouped:
         dev = torch.device('cuda', torch.cuda.current_device()) if torch.distributed.get_backend() == 'nccl' else 'cpu'
         verdict = torch.tensor([code], dtype=torch.int32, device=dev)
         torch.distributed.broadcast(verdict, src=0)
         code = int(verdict.item())
     if code != 0:
-        if world > 1:
+        if grouped:
             torch.distributed.destroy_process_group()
         sys.exit(code)
     return cache_path
@@ -290,7 +293,9 @@ def main(argv=None):
         print('k', ':', qkv['k'].shape)
         print(f'Computed qkv along {args.slice_along} in {time.time() - t0}s, saving now to: {cache_path}')
         save_features(qkv, cache_path)
-    if world > 1:
+    if world > 1 or torch.distributed.is_initialized():
+        if rank == 0:
+            print('slab exchanges:', ', '.join(f'{n} over {b}' for b, n in sorted(vt.extract.EXCHANGES.items())) or 'none')
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     sys.exit(0)

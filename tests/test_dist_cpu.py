@@ -71,11 +71,15 @@ def _worker(rank, world, port, shape, fos, seed, q):
     try:
         import vit_tf_amd as vt
         from helpers import tiny_model
+        if world == 1:       # a ONE-rank group still runs every call of the exchange (VITTF_DIST_FORCE=1 sets this at import)
+            vt.extract.DIST_FORCE = True
         oracle, _ = tiny_model(seed)
         vol = (torch.rand(shape, generator=torch.Generator().manual_seed(1)) * 2 - 1).half().float()
         ops = OracleOps(oracle)
         full = vt.feature_volume(vol, FakeModel(), fos, 'all', ops=ops)
         single = vt.feature_volume(vol, FakeModel(), fos, 'y', ops=ops)
+        if world == 1:
+            assert vt.extract.EXCHANGES == {'gloo': 4}, vt.extract.EXCHANGES       # z, y, x of 'all' + the single axis
         if rank == 0:
             q.put((full.numpy(), single.numpy()))       # by value: the producer may exit before the consumer reads
     finally:
@@ -95,7 +99,7 @@ def _free_port():
 # own ratio along x -- 512 slices -> 64 windows of 8 slices -> 8 windows per rank -- while its y and z axes have 2 windows
 # for 8 ranks (six ranks contribute an empty slab); (80, 16, 16): 10 windows over 8 ranks, chunk 2, three ranks without one.
 @pytest.mark.parametrize('shape,fos,world', [((24, 16, 32), 3, 2), ((10, 10, 10), 4, 2), ((24, 16, 32), 3, 4), ((10, 10, 10), 4, 4),
-                                             ((512, 16, 16), 2, 8), ((80, 16, 16), 2, 8)])
+                                             ((512, 16, 16), 2, 8), ((80, 16, 16), 2, 8), ((10, 10, 10), 4, 1)])
 def test_two_rank_sharding_matches_single_process_oracle(shape, fos, world):
     from oracle import feature_volume as ofv
     from helpers import tiny_model

@@ -341,6 +341,37 @@ def test_two_ranks_rccl(gpu, tmp_path):
     assert out['config']['dist_backend'] == 'nccl'
 
 
+def test_one_rank_rccl_exchange(gpu, tmp_path):
+    """The RCCL branch of the slab exchange on the hardware a one-GPU box has: infer.py with a ONE-rank `nccl` process group
+    (VITTF_DIST_FORCE=1; init_process_group('nccl', device_id=...) exactly as for N ranks, the verdict broadcast, three
+    in-place all_gather_into_tensor calls with async_op=True, their waits deferred to finish_exchanges, barrier, destroy)
+    must write the same bits as the plain single-process run.  What this does NOT cover: bytes moving between two GPUs
+    over xGMI (test_two_ranks_rccl, skipped below two GPUs)."""
+    vol, _ = vt.synthetic_volume('sphere_filled', 40, 0.2, 3)
+    np.save(tmp_path / 'v.npy', vol.numpy())
+    common = ['--data-path', str(tmp_path / 'v.npy'), '--feature-output-size', '5', '--synthetic-weights', '1']
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'VITTF_DIST_BACKEND', 'VITTF_DIST_FORCE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, 'infer.py', *common, '--cache-path', str(tmp_path / 'one.npy')], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert 'slab exchanges' not in r.stdout
+    env1 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(),
+                VITTF_DIST_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, 'infer.py', *common, '--cache-path', str(tmp_path / 'forced.npy')], cwd=ROOT, env=env1,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert 'slab exchanges: 3 over nccl' in r.stdout, r.stdout
+    one = np.load(tmp_path / 'one.npy', allow_pickle=True)[()]['k']
+    forced = np.load(tmp_path / 'forced.npy', allow_pickle=True)[()]['k']
+    assert one.shape == (384, 5, 5, 5) and np.array_equal(one, forced)
+    # the refusal to overwrite goes through the broadcast of the one-rank group as well
+    r = subprocess.run([sys.executable, 'infer.py', *common, '--cache-path', str(tmp_path / 'forced.npy')], cwd=ROOT, env=env1,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 1 and 'Cache file already exists' in r.stdout, r.stderr + r.stdout
+
+
 def test_vitb8_full_size_slice(gpu):
     """BASELINE configs[3] shape: ViT-B/8 (D = 768, 12 heads), N = 4097; one slice, bf16 and fp16 vs the oracle."""
     sd = vt.synthetic_state_dict('vitb8', 2)

@@ -57,6 +57,9 @@ def engine_batch_for(tokens, embed_dim, requested=None):
 # are those of the kernel alone.
 STREAM_LANES = int(__import__('os').environ.get('VITTF_STREAM_LANES', '1'))
 PARTS = {'q': 0, 'k': 1, 'v': 2}
+# VITTF_DIST_FORCE=1: run the slab exchange even when the process group has ONE rank (the collective then moves nothing, but
+# every call of the multi-rank path -- the in-place all_gather_into_tensor, its deferred wait -- executes on the backend)
+DIST_FORCE = __import__('os').environ.get('VITTF_DIST_FORCE', '0') == '1'
 
 
 def sizing(vol_shape, feature_output_size, patch_size):
@@ -207,7 +210,7 @@ def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=None, part=1,
     enqueued (RCCL runs it on its own stream while the next axis is computed) and the caller finishes it with
     `finish_exchanges(pending)` before it reads `gathered`."""
     world = torch.distributed.get_world_size(group) if _dist_on(group) else 1
-    rank = torch.distributed.get_rank(group) if world > 1 else 0
+    rank = torch.distributed.get_rank(group) if _dist_on(group) else 0
     sl, a, b, n_slices, f0, f1 = _axis_geometry(dvol.shape, im_sizes, axis, model.patch_size)
     d = model.embed_dim
     n = [0, 0, 0]
@@ -222,7 +225,7 @@ def axis_features(model, dvol, axis, im_sizes, n_out, engine_batch=None, part=1,
         kbuf = ops.k_slices(model, dvol, axis, im_sizes, s0, s1, engine_batch, part)
         ops.pool(model, kbuf, s0, n_slices, n_out, win0, nwin, f0, f1, d, slab, strides)
         del kbuf
-    if world > 1:
+    if _dist_on(group):
         handle = _all_gather_slabs(gathered, slab, group, defer=pending is not None)   # the one exchange step per axis
         if handle is not None:
             pending.append(handle)
@@ -236,6 +239,9 @@ def finish_exchanges(pending):
     pending.clear()
 
 
+EXCHANGES = {}       # backend -> slab exchanges enqueued by this process (infer.py prints it; the one-rank RCCL test reads it)
+
+
 def _all_gather_slabs(gathered, slab, group, defer=False):
     """All-gather the ranks' pooled slabs into `gathered` ([world, ...], this rank's slab already in place).
     RCCL (backend 'nccl') takes the single-tensor form -- asynchronously when `defer` is set: the (work, send buffer)
@@ -244,6 +250,7 @@ def _all_gather_slabs(gathered, slab, group, defer=False):
     world = gathered.shape[0]
     flat = gathered.view(world, -1)
     backend = torch.distributed.get_backend(group)
+    EXCHANGES[backend] = EXCHANGES.get(backend, 0) + 1
     if backend == 'nccl':
         # in place: this rank's slab already sits at flat[rank], which is exactly where an all-gather writes the rank's own
         # contribution (send buffer = receive buffer + rank * count, RCCL's in-place form): no staging copy
@@ -267,7 +274,7 @@ def _all_gather_slabs(gathered, slab, group, defer=False):
 
 def _dist_on(group):
     return torch.distributed.is_available() and torch.distributed.is_initialized() and \
-        torch.distributed.get_world_size(group) > 1
+        (torch.distributed.get_world_size(group) > 1 or DIST_FORCE)
 
 
 def assemble_axis(gathered, axis, n_total):

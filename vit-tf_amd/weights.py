@@ -227,14 +227,11 @@ def pack_block_tail_weights(wp, w1, w2):
     return torch.cat([_pack_row_images(wp), pack_mlp_weights(w1[:, :, order], w2)], dim=1).contiguous()
 
 
-def pack_mlp_weights(w1, w2):
-    """fc1 / fc2 weights of L blocks -> the stream the fused MLP kernel (csrc/mlp.hip) consumes: per block 96 images of
-    24 KB in consumption order W1(0), W1(1), W1(2), W2(0), W1(3), W2(1), .., W1(47), W2(45), W2(46), W2(47), each image = 6 sub-images of
-    [32 rows][64 k] in LDS layout, so that every LDS-DMA piece is 1 KB of contiguous memory.
-      W1(u): rows = hidden units 32 u .. + 31, k = the 384 inputs.
+def _mlp_images(w1, w2):
+    """fc1 / fc2 weights of L blocks as 24 KB LDS images, one per hidden unit of 32: (img1, img2), each [L, 48, 12288].
+      W1(u): rows = hidden units 32 u .. + 31, k = the 384 inputs: 6 sub-images [32 rows][64 k] (tile_off layout).
       W2(u): rows = outputs; sub-image s6 holds output tiles 2 s6 and 2 s6 + 1, 32 k each = hidden units 32 u .. + 31 in the
-             order the second MFMA finds them in the first one's accumulator registers (permute_fc2_hidden).
-    w1: [L, 4D, D], w2: [L, D, 4D] (16-bit, any device).  Returns [L, 96, 12288] of the same dtype."""
+             order the second MFMA finds them in the first one's accumulator registers (permute_fc2_hidden)."""
     L, hid, d = w1.shape
     assert d == 384 and hid == 4 * d and tuple(w2.shape) == (L, d, hid)
     units = hid // 32
@@ -249,11 +246,60 @@ def pack_mlp_weights(w1, w2):
     cols2 = (32 * torch.arange(units, device=dev).view(-1, 1, 1, 1) + 16 * ((c.view(1, 1, -1, 1) >> 1) & 1)
              + 8 * (c.view(1, 1, -1, 1) & 1) + e.view(1, 1, 1, -1))                                     # [U, 1, 256, 8]
     img2 = w2p[:, rows2.expand(units, 6, 256, 8), cols2.expand(units, 6, 256, 8)].reshape(L, units, -1)
+    return img1, img2
+
+
+def pack_mlp_weights(w1, w2):
+    """fc1 / fc2 weights of L blocks -> the stream the fused MLP kernel (csrc/mlp.hip) consumes: per block 96 images of
+    24 KB in consumption order W1(0), W1(1), W1(2), W2(0), W1(3), W2(1), .., W1(47), W2(45), W2(46), W2(47) (_mlp_images), so
+    that every LDS-DMA piece is 1 KB of contiguous memory.
+    w1: [L, 4D, D], w2: [L, D, 4D] (16-bit, any device).  Returns [L, 96, 12288] of the same dtype."""
+    img1, img2 = _mlp_images(w1, w2)
+    units = img1.shape[1]
     order = [('1', 0), ('1', 1)]
     for k in range(2, units):
         order += [('1', k), ('2', k - 2)]
     order += [('2', units - 2), ('2', units - 1)]
     return torch.stack([(img1 if t == '1' else img2)[:, u] for t, u in order], dim=1).contiguous()
+
+
+TAIL_FX_PSTEPS, TAIL_FX_MSTEPS, TAIL_FX_LAG = 12, 100, 4
+
+
+def _pack_proj_kmajor(wp):
+    """[L, 384, 384] -> [L, 12, 12288]: projection step p = k steps 2 p, 2 p + 1 of all 12 output tiles: fragment f (0 .. 23; the
+    kernel reads it at sub-image f >> 2, chunk pair f & 3) = Wp[32 (f % 12) + r][16 (2 p + f // 12) + 8 h + e]."""
+    L, n, d = wp.shape
+    assert n == 384 and d == 384
+    dev = wp.device
+    r, c = (t.to(dev) for t in _tile_pos_tables())
+    e = torch.arange(8, device=dev).view(1, 1, 1, -1)
+    s6 = torch.arange(6, device=dev).view(1, -1, 1, 1)
+    p = torch.arange(12, device=dev).view(-1, 1, 1, 1)
+    f = 4 * s6 + (c.view(1, 1, -1, 1) >> 1)                                 # [1, 6, 256, 1]
+    rows = 32 * (f % 12) + r.view(1, 1, -1, 1)
+    cols = 16 * (2 * p + f // 12) + 8 * (c.view(1, 1, -1, 1) & 1) + e        # [12, 6, 256, 8]
+    return wp[:, rows.expand(12, 6, 256, 8), cols.expand(12, 6, 256, 8)].reshape(L, 12, -1)
+
+
+def pack_tail_fx_weights(wp, w1, w2):
+    """proj / fc1 / fc2 weights of L blocks -> the stream of the role-split block-tail kernel (csrc/tail_fx.hip): per block
+    12 projection steps (K-major, _pack_proj_kmajor), then 100 main steps of 24 KB = [ W1(m >> 1) k half m & 1 | W2((m - 4) >> 1)
+    output-tile half (m - 4) & 1 ] (zeros where a role has no work: the first four W2 halves, the last four W1 halves); fc1's
+    input dim in the order norm2 leaves its values in the registers.  -> [L, 112, 12288]."""
+    L, d, d2 = wp.shape
+    assert d == 384 and d2 == 384
+    order = norm2_register_order().to(w1.device)
+    img1, img2 = _mlp_images(w1[:, :, order], w2)
+    half = img1.shape[-1] // 2
+    zero = torch.zeros_like(img1[:, 0, :half])
+    steps = []
+    for m in range(TAIL_FX_MSTEPS):
+        a = img1[:, m >> 1, (m & 1) * half:(m & 1) * half + half] if m < 96 else zero
+        m2 = m - TAIL_FX_LAG
+        b = img2[:, m2 >> 1, (m2 & 1) * half:(m2 & 1) * half + half] if m2 >= 0 else zero
+        steps.append(torch.cat([a, b], dim=-1))
+    return torch.cat([_pack_proj_kmajor(wp), torch.stack(steps, dim=1)], dim=1).contiguous()
 
 
 def permute_fc2_hidden(w2):
