@@ -230,6 +230,51 @@ def test_block_tail(gpu, dt, rows):
                                 _lib.ptr(xd), rows, 768, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()) == -1
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows', [1, 130, 4097, 128 * 300 + 77])
+def test_block_tail_fx_same_bits_as_one_wave_kernel(gpu, dt, rows):
+    """The role-split block tail (csrc/tail_fx.hip: X waves hold the fp32 rows, F waves the 16-bit rows) performs, per
+    accumulator, the SAME sequence of operations as the one-wave-per-SIMD kernel of csrc/mlp.hip (projection k steps in
+    ascending order, + residual, the same LayerNorm passes, fc1 over ascending k, the same GELU pieces, fc2 over ascending
+    hidden units): residual rows and the next LayerNorm's output must be bit-equal, guard rows untouched."""
+    lib = _lib.load()
+    d = 384
+    g = gen(rows + 11)
+    a = torch.randn(rows, d, generator=g).to(TDT[dt])
+    wp = (torch.randn(d, d, generator=g) / d ** 0.5).to(TDT[dt])
+    w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt])
+    w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
+    bp, b1, b2 = (0.3 * torch.randn(n, generator=g) for n in (d, 4 * d, d))
+    g2, e2 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    g1, e1 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    x0 = torch.randn(rows + GUARD_ROWS, d, generator=g) * 3
+    ctr = torch.zeros(1, dtype=torch.int32, device=gpu)
+    ad, wpd, bpd, w1d, b1d, w2d, b2d, g2d, e2d, g1d, e1d = (t.to(gpu) for t in (a, wp, bp, w1, b1, w2, b2, g2, e2, g1, e1))
+    wold = vt.weights.pack_block_tail_weights(wpd[None], w1d[None], w2d[None])[0].contiguous()
+    wfx = vt.weights.pack_tail_fx_weights(wpd[None], w1d[None], w2d[None])[0].contiguous()
+    assert wfx.shape == (112, 12288)
+    outs = []
+    for fn, w in ((lib.vittf_block_tail, wold), (lib.vittf_block_tail_fx, wfx)):
+        xd = x0.to(gpu)
+        hout = torch.full((rows + GUARD_ROWS, d), 7.0, dtype=TDT[dt], device=gpu)
+        _lib.check(fn(_lib.ptr(ad), _lib.ptr(w), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(xd), rows, d,
+                      _lib.DTYPES[dt], _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(hout), _lib.ptr(ctr), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((xd, hout))
+    (x_old, h_old), (x_new, h_new) = outs
+    assert torch.equal(x_new[rows:].cpu(), x0[rows:]), 'wrote past the last row'
+    assert (h_new[rows:].float() == 7.0).all(), 'wrote past the last row of h'
+    assert torch.equal(x_new, x_old), f'{int((x_new != x_old).sum())} residual values differ'
+    assert torch.equal(h_new, h_old)
+    # without the LayerNorm on the way out: the same residual rows, nothing else written
+    x3 = x0.to(gpu)
+    _lib.check(lib.vittf_block_tail_fx(_lib.ptr(ad), _lib.ptr(wfx), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
+                                       _lib.ptr(x3), rows, d, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()))
+    assert torch.equal(x3, x_new)
+    assert lib.vittf_block_tail_fx(_lib.ptr(ad), _lib.ptr(wfx), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
+                                   _lib.ptr(x3), rows, 768, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()) == -1
+
+
 def test_block_tail_two_streams_caller_owned_counters(gpu):
     """The library keeps no state of its own for the block tail: two calls in flight at once on two streams, each with its OWN
     tile counter (caller memory, vittf_block_tail_workspace_bytes()), write the same bits as the same calls one after the

@@ -284,9 +284,10 @@ def _pack_proj_kmajor(wp):
 
 def pack_tail_fx_weights(wp, w1, w2):
     """proj / fc1 / fc2 weights of L blocks -> the stream of the role-split block-tail kernel (csrc/tail_fx.hip): per block
-    12 projection steps (K-major, _pack_proj_kmajor), then 100 main steps of 24 KB = [ W1(m >> 1) k half m & 1 | W2((m - 4) >> 1)
-    output-tile half (m - 4) & 1 ] (zeros where a role has no work: the first four W2 halves, the last four W1 halves); fc1's
-    input dim in the order norm2 leaves its values in the registers.  -> [L, 112, 12288]."""
+    12 projection steps of 24 KB (k steps 2 p, 2 p + 1 of all output tiles, K-major: _pack_proj_kmajor), then 100 main steps =
+    [ W1(m >> 1) k half m & 1 | W2((m - 4) >> 1) output-tile half (m - 4) & 1 ] (zeros where a role has no work: the first four
+    W2 halves, the last four W1 halves); fc1's input dim in the order norm2 leaves its values in the registers.
+    -> [L, 112, 12288]."""
     L, d, d2 = wp.shape
     assert d == 384 and d2 == 384
     order = norm2_register_order().to(w1.device)
