@@ -275,6 +275,55 @@ def test_block_tail_fx_same_bits_as_one_wave_kernel(gpu, dt, rows):
                                    _lib.ptr(x3), rows, 768, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()) == -1
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows', [1, 130, 4097, 128 * 300 + 77])
+def test_block_tail_qkv_same_bits_as_separate_launches(gpu, dt, rows):
+    """vittf_block_tail_qkv = the block tail + the NEXT block's qkv projection of the new rows in one launch: residual rows
+    and LayerNorm output bit-equal to vittf_block_tail, the qkv rows bit-equal to the stand-alone GEMM on that LayerNorm
+    output (vittf_gemm, VITTF_EPI_BIAS_QKV: q third pre-scaled by log2(e) / 8); guard rows of all three outputs untouched."""
+    lib = _lib.load()
+    d = 384
+    g = gen(rows + 23)
+    a = torch.randn(rows, d, generator=g).to(TDT[dt])
+    wp = (torch.randn(d, d, generator=g) / d ** 0.5).to(TDT[dt])
+    w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt])
+    w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
+    wq = (1.3 * torch.randn(3 * d, d, generator=g) / d ** 0.5).to(TDT[dt])
+    bp, b1, b2, bq = (0.3 * torch.randn(n, generator=g) for n in (d, 4 * d, d, 3 * d))
+    g2, e2 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    g1, e1 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    x0 = torch.randn(rows + GUARD_ROWS, d, generator=g) * 3
+    ctr = torch.zeros(1, dtype=torch.int32, device=gpu)
+    ad, wpd, bpd, w1d, b1d, w2d, b2d, g2d, e2d, g1d, e1d, wqd, bqd = (t.to(gpu) for t in (a, wp, bp, w1, b1, w2, b2, g2, e2, g1, e1, wq, bq))
+    wold = vt.weights.pack_block_tail_weights(wpd[None], w1d[None], w2d[None])[0].contiguous()
+    wfq = vt.weights.pack_tail_fx_qkv_weights(wpd[None], w1d[None], w2d[None], wqd[None])[0].contiguous()
+    assert wfq.shape == (172, 12288)
+    x_old = x0.to(gpu)
+    h_old = torch.full((rows + GUARD_ROWS, d), 7.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wold), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
+                                    _lib.ptr(x_old), rows, d, _lib.DTYPES[dt], _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h_old), _lib.ptr(ctr),
+                                    _lib.stream_ptr()))
+    q_old = torch.full((rows + GUARD_ROWS, 3 * d), 5.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_gemm(_lib.ptr(h_old), _lib.ptr(wqd), _lib.ptr(bqd), _lib.ptr(q_old), rows, 3 * d, d, _lib.EPI_BIAS_QKV, 0, _lib.DTYPES[dt],
+                              _lib.stream_ptr()))
+    x_new = x0.to(gpu)
+    h_new = torch.full((rows + GUARD_ROWS, d), 7.0, dtype=TDT[dt], device=gpu)
+    q_new = torch.full((rows + GUARD_ROWS, 3 * d), 5.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_block_tail_qkv(_lib.ptr(ad), _lib.ptr(wfq), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
+                                        _lib.ptr(x_new), rows, d, _lib.DTYPES[dt], _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h_new),
+                                        _lib.ptr(bqd), _lib.ptr(q_new), _lib.ptr(ctr), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(x_new[rows:].cpu(), x0[rows:]), 'wrote past the last row of x'
+    assert (h_new[rows:].float() == 7.0).all() and (q_new[rows:].float() == 5.0).all(), 'wrote past the last row of h / qkv'
+    assert torch.equal(x_new, x_old), f'{int((x_new != x_old).sum())} residual values differ'
+    assert torch.equal(h_new, h_old)
+    assert torch.equal(q_new[:rows], q_old[:rows]), f'{int((q_new[:rows] != q_old[:rows]).sum())} qkv values differ'
+    # arguments the entry refuses
+    assert lib.vittf_block_tail_qkv(_lib.ptr(ad), _lib.ptr(wfq), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
+                                    _lib.ptr(x_new), rows, d, _lib.DTYPES[dt], _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h_new),
+                                    None, _lib.ptr(q_new), _lib.ptr(ctr), _lib.stream_ptr()) == -1
+
+
 def test_block_tail_two_streams_caller_owned_counters(gpu):
     """The library keeps no state of its own for the block tail: two calls in flight at once on two streams, each with its OWN
     tile counter (caller memory, vittf_block_tail_workspace_bytes()), write the same bits as the same calls one after the

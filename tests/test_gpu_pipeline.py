@@ -240,6 +240,27 @@ def test_entry_points_end_to_end(gpu, tmp_path):
     feats = np.load(out, allow_pickle=True)[()]
     assert set(feats) == {'k'} and feats['k'].dtype == np.float16 and feats['k'].shape == (384, 8, 8, 8)
     assert np.isfinite(feats['k'].astype(np.float32)).all()
+    # the path a user with a real checkpoint takes: --weights FILE (a DINO training checkpoint: teacher / backbone. wrappers and
+    # a projection head that must be dropped), and the same file through $VITTF_WEIGHTS -- the loader-to-engine path on the
+    # GPU must give the bits of the same state dict handed over in memory
+    sd = vt.synthetic_state_dict('vits8', 0)
+    ckpt = {'teacher': {**{'backbone.' + k: v for k, v in sd.items()}, 'head.mlp.0.weight': torch.zeros(8, 384),
+                        'head.last_layer.weight_g': torch.ones(4, 1)},
+            'student': {'module.backbone.' + k: torch.zeros_like(v) for k, v in sd.items()}, 'epoch': 3}
+    torch.save(ckpt, d / 'dino_ckpt.pth')
+    wcommon = [a for a in common if a not in ('--synthetic-weights', '0')]
+    r = run('infer.py', *wcommon, '--weights', str(d / 'dino_ckpt.pth'), '--cache-path', str(d / 'from_weights.npy'))
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert 'synthetic' not in r.stdout
+    fw = np.load(d / 'from_weights.npy', allow_pickle=True)[()]
+    assert np.array_equal(fw['k'], feats['k']), '--weights FILE and the in-memory state dict give different features'
+    r = subprocess.run([sys.executable, 'infer.py', *wcommon, '--cache-path', str(d / 'from_env.npy')], cwd=ROOT,
+                       env=dict(env, VITTF_WEIGHTS=str(d / 'dino_ckpt.pth')), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert np.array_equal(np.load(d / 'from_env.npy', allow_pickle=True)[()]['k'], feats['k'])
+    assert run('infer.py', *wcommon, '--cache-path', str(d / 'none.npy')).returncode == 1      # no weights at all: exit 1, no download
+    for f in ('from_weights.npy', 'from_env.npy', 'dino_ckpt.pth'):
+        os.unlink(d / f)
     r = run('infer.py', *common)                                   # cache exists, no --overwrite -> exit 1
     assert r.returncode == 1 and 'Cache file already exists' in r.stdout
     assert run('infer.py', *common, '--cpu', '--overwrite').returncode == 1

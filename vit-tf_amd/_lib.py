@@ -71,6 +71,7 @@ SIGNATURES = {
     'vittf_block_tail_workspace_bytes': (_sz, []),
     'vittf_block_tail': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     'vittf_block_tail_fx': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
+    'vittf_block_tail_qkv': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vittf_attention_rescale_count': (_i64, [_i32]),
     'vittf_attention_fp8_workspace_bytes': (_sz, [_i32, _i32, _i32]),

@@ -26,6 +26,8 @@
 #include "vittf_common.h"
 
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -63,6 +65,16 @@ constexpr int LDS_BYTES = NEXT_OFF + 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 static_assert(AHEAD >= 3, "ring depth");
 static_assert(32 * STG_ROW <= PBH && 4 * AF_SLOT <= PBH, "pair buffer");
+// ---- the form with the NEXT block's qkv projection folded in (QKV = true; run_fq / run_xq below)
+constexpr int BSTEPS = 72;                   // boundary steps of a row tile: the F wave runs one k half of a qkv unit in each
+constexpr int QUNITS = 3 * D / 32;           // 36 output tiles of 32 qkv columns
+constexpr int NSEQ_Q = BSTEPS + MSTEPS;
+constexpr int PBQ = 3 * PBH;                 // pair region: half 0 | half 1 | the F wave's output staging
+constexpr int CQ_OFF = PB_OFF + 4 * PBQ;     // constants, in floats: b2 | gamma, beta of the next norm1 | proj bias | gamma, beta of norm2
+constexpr int CQ_B2 = 0, CQ_G1 = D, CQ_E1 = 2 * D, CQ_BP = 3 * D, CQ_G2 = 4 * D, CQ_E2 = 5 * D, CQ_N = 6 * D;
+constexpr int NEXTQ_OFF = CQ_OFF + CQ_N * 4;
+constexpr int LDSQ_BYTES = NEXTQ_OFF + 16;
+static_assert(LDSQ_BYTES <= 160 * 1024, "LDS (qkv form)");
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
@@ -75,10 +87,11 @@ typedef __attribute__((address_space(3))) volatile unsigned* lds_u32_ptr;
 
 struct Ring {                  // where the weight stream stands (wave-uniform)
   i32x4_t rsrc;                // descriptor over one layer's NSEQ packed steps
-  unsigned dma_dst;            // LDS byte address of this wave's first piece in slot 0
-  int src0;                    // byte offset of this wave's first piece inside a step
-  int g;                       // stream position of the step being computed (0 .. NSEQ - 1, wraps with the row tiles)
+  unsigned dma_dst;            // LDS byte address of slot 0
+  int src0, src_hi;            // byte offsets inside a step of this wave's pieces 0 .. 2 / 3 .. 5
+  int g;                       // stream position of the step being computed (0 .. nseq - 1, wraps with the row tiles)
   int slot;                    // its ring slot
+  int nseq;                    // steps per row tile
 };
 
 __device__ __forceinline__ s16x8_t ld_frag(const unsigned (&base)[4], int f) {
@@ -157,16 +170,17 @@ __device__ __forceinline__ void sync_wait() {
   else asm volatile("s_barrier" ::: "memory");
 }
 
-__device__ __forceinline__ int ring_next(const Ring& st) { return st.g + AHEAD < NSEQ ? st.g + AHEAD : st.g + AHEAD - NSEQ; }
+__device__ __forceinline__ int ring_next(const Ring& st) { return st.g + AHEAD < st.nseq ? st.g + AHEAD : st.g + AHEAD - st.nseq; }
 __device__ __forceinline__ int ring_free(const Ring& st) { return st.slot == 0 ? NSLOT - 1 : st.slot - 1; }
 __device__ __forceinline__ void ring_advance(Ring& st) {
-  st.g = st.g + 1 == NSEQ ? 0 : st.g + 1;
+  st.g = st.g + 1 == st.nseq ? 0 : st.g + 1;
   st.slot = st.slot + 1 == NSLOT ? 0 : st.slot + 1;
 }
 // piece i (0 .. 5) of this X wave for the step AHEAD, into the slot the barrier of this step has freed
 __device__ __forceinline__ void ring_piece(const Ring& st, int i, int g_next, int slot_free) {
   if (V_NO_DMA) return;
-  lds_dma16_keep(st.rsrc, st.dma_dst + slot_free * SB + i * 1024, (int)((threadIdx.x & 63) * 16), g_next * SB + st.src0 + i * 1024);
+  const int off = i < 3 ? st.src0 + i * 1024 : st.src_hi + (i - 3) * 1024;
+  lds_dma16_keep(st.rsrc, st.dma_dst + slot_free * SB + off, (int)((threadIdx.x & 63) * 16), g_next * SB + off);
 }
 __device__ __forceinline__ void rotate_bases(const Ring& st, unsigned (&base)[4]) {
   const int d_ = st.slot == NSLOT - 1 ? -(NSLOT - 1) * SB : SB;
@@ -277,13 +291,14 @@ __device__ __forceinline__ constexpr int af_off(int s) { return (((s >> 2) & 1) 
 struct Ctx {
   const unsigned short* abuf; const unsigned short* wpk; float* x; unsigned short* hout; unsigned* tile_ctr;
   int64_t rows; float ln_eps; int ntiles; int tile; unsigned lds0;
+  unsigned short* qkv_out; const float* qkv_b; const float* b1;      // (qkv form only)
 };
 __device__ __forceinline__ unsigned uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) {
   const uint64_t v = reinterpret_cast<uint64_t>(p);
   return reinterpret_cast<T*>(((uint64_t)uni((unsigned)(v >> 32)) << 32) | uni((unsigned)v));
 }
-#define FX_ROLE_ENV                                                                                                       \
+#define FX_ROLE_ENV(QKV_)                                                                                                 \
   const unsigned short* const abuf = uni_ptr(c.abuf);                                                                     \
   float* const x = uni_ptr(c.x);                                                                                          \
   unsigned short* const hout = uni_ptr(c.hout);                                                                           \
@@ -297,22 +312,24 @@ template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                             \
   const int rb = wave & 3;                                                                                                \
   const int h = lane >> 5, l31 = lane & 31;                                                                               \
-  unsigned cl = lds0 + CONST_OFF + 16 * h;                                                                                \
+  unsigned cl = lds0 + ((QKV_) ? CQ_OFF : CONST_OFF) + 16 * h;                                                            \
   asm volatile("" : "+v"(cl));                                                                                            \
   auto cst4 = [&](int i) { return *(lds_f4_ptr)(cl + 4 * i); };      /* floats i .. i + 3 (+ 4 h) of the constants */       \
-  const unsigned nxt = lds0 + NEXT_OFF;                                                                                   \
+  const unsigned nxt = lds0 + ((QKV_) ? NEXTQ_OFF : NEXT_OFF);                                                            \
   Ring st;                                                                                                                \
-  st.rsrc = lds_dma_rsrc(uni_ptr(c.wpk), (unsigned)(NSEQ * SB));                                                          \
-  st.src0 = rb * (PIECES * 1024);                                                                                         \
-  st.dma_dst = lds0 + rb * (PIECES * 1024);                                                                               \
+  st.nseq = (QKV_) ? NSEQ_Q : NSEQ;                                                                                       \
+  st.rsrc = lds_dma_rsrc(uni_ptr(c.wpk), (unsigned)(st.nseq * SB));                                                       \
+  st.src0 = (QKV_) ? rb * 3072 : rb * 6144;           /* qkv form: three pieces of each half of a step per X wave */       \
+  st.src_hi = (QKV_) ? HB + rb * 3072 : rb * 6144 + 3072;                                                                 \
+  st.dma_dst = lds0;                                                                                                      \
   st.g = 0;                                                                                                               \
   st.slot = 0;                                                                                                            \
   const int aoff0 = tile_off(l31, h);                                                                                     \
-  const unsigned pbuf = lds0 + PB_OFF + rb * PB;      /* this pair's buffer: halves at + 0 and + PBH */                     \
+  const unsigned pbuf = lds0 + PB_OFF + rb * ((QKV_) ? PBQ : PB);      /* this pair's buffer: halves at + 0 and + PBH */    \
   /* a tile's slice of a [rows][width bytes] array as a buffer descriptor: rows past the end read as zero / are not written */ \
   auto tile_rsrc = [&](const void* p, int64_t tile, int row_bytes) {                                                      \
     const int64_t first = tile * 128, left = rows - first;                                                                \
-    const int nrows = left <= 0 || !p ? 0 : left < 128 ? (int)left : 128;                                                 \
+    const int nrows = tile < 0 || left <= 0 || !p ? 0 : left < 128 ? (int)left : 128;                                     \
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p)) + (nrows ? first : 0) * row_bytes, 0, \
                                              nrows * row_bytes, 0x00020000);                                              \
   };                                                                                                                      \
@@ -323,7 +340,7 @@ template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) {
 // =============================================== F: the 16-bit rows ===============================================
 template <int DT>
 __device__ __attribute__((noinline)) void run_f(Ctx c) {
-  FX_ROLE_ENV;
+  FX_ROLE_ENV(false);
   // =============================================== F: the 16-bit rows ===============================================
   if (!V_NO_PRIO) asm volatile("s_setprio 3");     // its GELU pieces go in front of the X wave's MFMA waiting for the pipe
   unsigned pbl = pbuf + lane * 16;                 // lane-linear 16-byte slots of the pair buffer
@@ -483,7 +500,7 @@ __device__ __attribute__((noinline)) void run_f(Ctx c) {
 // =============================================== X: the fp32 rows ===============================================
 template <int DT>
 __device__ __attribute__((noinline)) void run_x(Ctx c) {
-  FX_ROLE_ENV;
+  FX_ROLE_ENV(false);
   // =============================================== X: the fp32 rows ===============================================
   unsigned base[4];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -748,37 +765,48 @@ __device__ __attribute__((noinline)) void run_x(Ctx c) {
   }
 }
 
-template <int DT>
+#include "tail_fx_qkv.inc"
+
+template <int DT, bool QKV>
 __global__ __launch_bounds__(512, 1) void tail_fx_kernel(const unsigned short* __restrict__ abuf, const unsigned short* __restrict__ wpk,
                                                          const float* __restrict__ bp, const float* __restrict__ g2, const float* __restrict__ e2,
                                                          const float* __restrict__ b1, const float* __restrict__ b2,
                                                          float* __restrict__ x, int64_t rows, const float* __restrict__ ln_g,
                                                          const float* __restrict__ ln_b, float ln_eps,
                                                          unsigned short* __restrict__ hout, int ntiles,
-                                                         unsigned* __restrict__ tile_ctr) {
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+                                                         unsigned* __restrict__ tile_ctr, const float* __restrict__ qkv_b,
+                                                         unsigned short* __restrict__ qkv_out) {
+  __shared__ __attribute__((aligned(16))) char smem[QKV ? LDSQ_BYTES : LDS_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* const cst = reinterpret_cast<float*>(smem + CONST_OFF);
-  for (int i = tid; i < C_N; i += 512) {
-    float v;
-    if (i < C_B2) v = b1[i];
-    else if (i < C_G1) v = b2[i - C_B2];
-    else if (i < C_E1) v = ln_g ? ln_g[i - C_G1] : 1.f;
-    else if (i < C_BP) v = ln_b ? ln_b[i - C_E1] : 0.f;
-    else if (i < C_G2) v = bp[i - C_BP];
-    else if (i < C_E2) v = g2[i - C_G2];
-    else v = e2[i - C_E2];
-    cst[i] = v;
+  if constexpr (QKV) {
+    float* const cst = reinterpret_cast<float*>(smem + CQ_OFF);
+    for (int i = tid; i < CQ_N; i += 512) {
+      const int k = i / D, j = i - k * D;
+      cst[i] = k == 0 ? b2[j] : k == 1 ? ln_g[j] : k == 2 ? ln_b[j] : k == 3 ? bp[j] : k == 4 ? g2[j] : e2[j];
+    }
+  } else {
+    float* const cst = reinterpret_cast<float*>(smem + CONST_OFF);
+    for (int i = tid; i < C_N; i += 512) {
+      float v;
+      if (i < C_B2) v = b1[i];
+      else if (i < C_G1) v = b2[i - C_B2];
+      else if (i < C_E1) v = ln_g ? ln_g[i - C_G1] : 1.f;
+      else if (i < C_BP) v = ln_b ? ln_b[i - C_E1] : 0.f;
+      else if (i < C_G2) v = bp[i - C_BP];
+      else if (i < C_E2) v = g2[i - C_G2];
+      else v = e2[i - C_E2];
+      cst[i] = v;
+    }
   }
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
-  const unsigned nxt = lds0 + NEXT_OFF;
+  const unsigned nxt = lds0 + (QKV ? NEXTQ_OFF : NEXT_OFF);
   if (tid == 0) *(lds_u32_ptr)nxt = atomicAdd(tile_ctr, 1u);
   __syncthreads();
   const int tile = __builtin_amdgcn_readfirstlane((int)*(lds_u32_ptr)nxt);
   if (tile >= ntiles) return;                  // (nothing requested yet)
   if (wave < 4) {                              // the first AHEAD steps of the weight stream (X waves: six pieces per step each)
-    const i32x4_t rsrc = lds_dma_rsrc(wpk, (unsigned)(NSEQ * SB));
+    const i32x4_t rsrc = lds_dma_rsrc(wpk, (unsigned)((QKV ? NSEQ_Q : NSEQ) * SB));
 #pragma unroll
     for (int u = 0; u < AHEAD; ++u)
 #pragma unroll
@@ -792,9 +820,14 @@ __global__ __launch_bounds__(512, 1) void tail_fx_kernel(const unsigned short* _
     g_fx_hwid[wave] = hw;
   }
 #endif
-  const Ctx c = {abuf, wpk, x, hout, tile_ctr, rows, ln_eps, ntiles, tile, lds0};
-  if (wave >= 4) run_f<DT>(c);
-  else run_x<DT>(c);
+  const Ctx c = {abuf, wpk, x, hout, tile_ctr, rows, ln_eps, ntiles, tile, lds0, qkv_out, qkv_b, b1};
+  if constexpr (QKV) {
+    if (wave >= 4) run_fq<DT>(c);
+    else run_xq<DT>(c);
+  } else {
+    if (wave >= 4) run_f<DT>(c);
+    else run_x<DT>(c);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the steps requested beyond the last one: land before the LDS goes away
 }
 
@@ -812,16 +845,14 @@ extern "C" int vittf_fx_stamps(unsigned long long* out, unsigned* hwid) {
 void vittf_note_kernel(int, const char*) {}
 #endif
 
-extern "C" int vittf_block_tail_fx(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g,
-                                   const float* ln2_b, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
-                                   int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* tile_counter,
-                                   void* stream) {
-  if (!attn_out || !w_packed || !proj_b || !ln2_g || !ln2_b || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
-  if (d != D) return VITTF_ERR_INVALID_ARG;
-  if ((ln_g || ln_b || h_out) && !(ln_g && ln_b && h_out)) return VITTF_ERR_INVALID_ARG;
+static int tail_fx_launch(bool qkv, const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g,
+                          const float* ln2_b, const float* b1, const float* b2, float* x, int64_t rows, int32_t dtype,
+                          const float* ln_g, const float* ln_b, float ln_eps, void* h_out, const float* qkv_b, void* qkv_out,
+                          void* tile_counter, void* stream) {
   const int64_t tiles = (rows + 127) / 128;
   if (tiles > 0x7fffffff) return VITTF_ERR_INVALID_ARG;
-  if ((((uintptr_t)attn_out | (uintptr_t)w_packed | (uintptr_t)x | (uintptr_t)h_out) & 15) != 0) return VITTF_ERR_INVALID_ARG;
+  if ((((uintptr_t)attn_out | (uintptr_t)w_packed | (uintptr_t)x | (uintptr_t)h_out | (uintptr_t)qkv_out | (uintptr_t)qkv_b | (uintptr_t)b1) & 15) != 0)
+    return VITTF_ERR_INVALID_ARG;
   if (!tile_counter || ((uintptr_t)tile_counter & 3) != 0) return VITTF_ERR_INVALID_ARG;
   const int cus = vittf_current_cus();
   if (cus <= 0) return VITTF_ERR_NO_DEVICE;
@@ -832,14 +863,39 @@ extern "C" int vittf_block_tail_fx(const void* attn_out, const void* w_packed, c
   hipStream_t st = (hipStream_t)stream;
   unsigned* ctr = (unsigned*)tile_counter;
   if (hipMemsetAsync(ctr, 0, sizeof(unsigned), st) != hipSuccess) return VITTF_ERR_LAUNCH;
-#define FX_LAUNCH(DTV)                                                                                               \
-  hipLaunchKernelGGL((tail_fx_kernel<DTV>), dim3(grid), dim3(512), 0, st, (const unsigned short*)attn_out,           \
+#define FX_LAUNCH(DTV, QV)                                                                                           \
+  hipLaunchKernelGGL((tail_fx_kernel<DTV, QV>), dim3(grid), dim3(512), 0, st, (const unsigned short*)attn_out,       \
                      (const unsigned short*)w_packed, proj_b, ln2_g, ln2_b, b1, b2, x, rows, ln_g, ln_b, ln_eps,     \
-                     (unsigned short*)h_out, (int)tiles, ctr)
-  if (dtype == VITTF_BF16) FX_LAUNCH(VITTF_BF16);
-  else if (dtype == VITTF_FP16) FX_LAUNCH(VITTF_FP16);
+                     (unsigned short*)h_out, (int)tiles, ctr, qkv_b, (unsigned short*)qkv_out)
+  if (dtype == VITTF_BF16) { if (qkv) FX_LAUNCH(VITTF_BF16, true); else FX_LAUNCH(VITTF_BF16, false); }
+  else if (dtype == VITTF_FP16) { if (qkv) FX_LAUNCH(VITTF_FP16, true); else FX_LAUNCH(VITTF_FP16, false); }
   else return VITTF_ERR_INVALID_ARG;
 #undef FX_LAUNCH
-  vittf_note_kernel(VITTF_KERNEL_MLP, "tail_fx_kernel");
+  vittf_note_kernel(VITTF_KERNEL_MLP, qkv ? "tail_fx_kernel<qkv>" : "tail_fx_kernel");
   return vittf_check_launch();
+}
+
+extern "C" int vittf_block_tail_fx(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g,
+                                   const float* ln2_b, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
+                                   int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* tile_counter,
+                                   void* stream) {
+  if (!attn_out || !w_packed || !proj_b || !ln2_g || !ln2_b || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
+  if (d != D) return VITTF_ERR_INVALID_ARG;
+  if ((ln_g || ln_b || h_out) && !(ln_g && ln_b && h_out)) return VITTF_ERR_INVALID_ARG;
+  return tail_fx_launch(false, attn_out, w_packed, proj_b, ln2_g, ln2_b, b1, b2, x, rows, dtype, ln_g, ln_b, ln_eps, h_out, nullptr,
+                        nullptr, tile_counter, stream);
+}
+
+// ... and the next block's qkv projection of the new rows in the same launch: qkv_out[rows][3 d] = LayerNorm(x_new; ln_g, ln_b) .
+// Wqkv^T + qkv_b, the q third multiplied by log2(e) / 8 (= vittf_gemm(h_out, ..., VITTF_EPI_BIAS_QKV), bit for bit); w_packed is
+// the stream of weights.pack_tail_fx_qkv_weights (this block's proj / fc1 / fc2 and the NEXT block's qkv weight).
+extern "C" int vittf_block_tail_qkv(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g,
+                                    const float* ln2_b, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
+                                    int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out,
+                                    const float* qkv_b, void* qkv_out, void* tile_counter, void* stream) {
+  if (!attn_out || !w_packed || !proj_b || !ln2_g || !ln2_b || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
+  if (!ln_g || !ln_b || !h_out || !qkv_b || !qkv_out) return VITTF_ERR_INVALID_ARG;
+  if (d != D) return VITTF_ERR_INVALID_ARG;
+  return tail_fx_launch(true, attn_out, w_packed, proj_b, ln2_g, ln2_b, b1, b2, x, rows, dtype, ln_g, ln_b, ln_eps, h_out, qkv_b,
+                        qkv_out, tile_counter, stream);
 }

@@ -303,6 +303,45 @@ def pack_tail_fx_weights(wp, w1, w2):
     return torch.cat([_pack_proj_kmajor(wp), torch.stack(steps, dim=1)], dim=1).contiguous()
 
 
+def _pack_proj_kstep_halves(wp):
+    """[L, 384, 384] -> [L, 24, 6144]: the projection one k step at a time: fragment f (0 .. 11; sub-image f >> 2, chunk pair
+    f & 3 of the X half of a step) = Wp[32 f + r][16 p + 8 h + e]."""
+    L, n, d = wp.shape
+    assert n == 384 and d == 384
+    dev = wp.device
+    r, c = (t.to(dev) for t in _tile_pos_tables())
+    e = torch.arange(8, device=dev).view(1, 1, 1, -1)
+    s3 = torch.arange(3, device=dev).view(1, -1, 1, 1)
+    p = torch.arange(24, device=dev).view(-1, 1, 1, 1)
+    f = 4 * s3 + (c.view(1, 1, -1, 1) >> 1)                                 # [1, 3, 256, 1]
+    rows = 32 * f + r.view(1, 1, -1, 1)
+    cols = 16 * p + 8 * (c.view(1, 1, -1, 1) & 1) + e                        # [24, 1, 256, 8]
+    return wp[:, rows.expand(24, 3, 256, 8), cols.expand(24, 3, 256, 8)].reshape(L, 24, -1)
+
+
+TAIL_FXQ_BSTEPS = 72
+
+
+def pack_tail_fx_qkv_weights(wp, w1, w2, wqkv_next):
+    """The stream of vittf_block_tail_qkv (csrc/tail_fx_qkv.inc): per block 72 boundary steps of 24 KB = [ k half s & 1 of the
+    NEXT block's qkv rows 32 (s >> 1) .. (natural k order: the sums of the stand-alone GEMM) | for s = 12 .. 35 this block's
+    projection k step s - 12, zeros elsewhere ], then the 100 main steps of pack_tail_fx_weights.
+    wp: [L, D, D], w1: [L, 4D, D], w2: [L, D, 4D], wqkv_next: [L, 3D, D] (block l + 1's weight at index l) -> [L, 172, 12288]."""
+    L, d, d2 = wp.shape
+    assert d == 384 and d2 == 384 and tuple(wqkv_next.shape) == (L, 3 * d, d)
+    imgq = _pack_row_images(wqkv_next)                      # [L, 36, 12288]
+    half = imgq.shape[-1] // 2
+    pj = _pack_proj_kstep_halves(wp)                        # [L, 24, 6144]
+    zero = torch.zeros_like(pj[:, 0])
+    steps = []
+    for s_ in range(TAIL_FXQ_BSTEPS):
+        a = imgq[:, s_ >> 1, (s_ & 1) * half:(s_ & 1) * half + half]
+        b = pj[:, s_ - 12] if 12 <= s_ < 36 else zero
+        steps.append(torch.cat([a, b], dim=-1))
+    main = pack_tail_fx_weights(wp, w1, w2)[:, TAIL_FX_PSTEPS:]
+    return torch.cat([torch.stack(steps, dim=1), main], dim=1).contiguous()
+
+
 def permute_fc2_hidden(w2):
     """fc2 weight [..., D, 4D] with its hidden (input) dim re-ordered inside every block of 16: the k order in which
     the fused MLP kernel's second MFMA consumes the first one's accumulator registers (include/vittf.h, fc2_w_perm)."""
