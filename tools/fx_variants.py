@@ -17,6 +17,7 @@ from vit_tf_amd import _lib  # noqa: E402
 
 ARGS = ([ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
+ARGS_Q = ARGS[:15] + [ctypes.c_void_p, ctypes.c_void_p] + ARGS[15:]
 
 
 def main():
@@ -37,7 +38,24 @@ def main():
     ctr = torch.zeros(1, dtype=torch.int32, device=dev)
     fns = []
     lib = _lib.load()
+    wq = (1.3 * torch.randn(3 * d, d, generator=g) / d ** 0.5).half().to(dev)
+    bq = torch.randn(3 * d, generator=g).to(dev)
+    qkv = torch.empty(rows, 3 * d, dtype=torch.float16, device=dev)
+    wfq = vt.weights.pack_tail_fx_qkv_weights(wp[None], w1[None], w2[None], wq[None])[0].contiguous()
+
+    def old_plus_gemm(*a):          # what the engine runs today: the one-wave block tail, then the qkv GEMM on its LayerNorm output
+        rc = lib.vittf_block_tail(*a)
+        return rc or lib.vittf_gemm(hn.data_ptr(), wq.data_ptr(), bq.data_ptr(), qkv.data_ptr(), rows, 3 * d, d, _lib.EPI_BIAS_QKV, 0,
+                                    _lib.DTYPES['fp16'], _lib.stream_ptr())
+
+    def q_entry(f):
+        f.restype = ctypes.c_int
+        f.argtypes = ARGS_Q
+        return lambda *a: f(*a[:15], bq.data_ptr(), qkv.data_ptr(), *a[15:])
     fns.append(('lib:mlp.hip', lib.vittf_block_tail, wold, None))
+    fns.append(('lib:mlp+qkvgemm', old_plus_gemm, wold, None))
+    if hasattr(lib, 'vittf_block_tail_qkv') and os.environ.get('FX_LIB', '1') == '1':
+        fns.append(('lib:tail_qkv', q_entry(lib.vittf_block_tail_qkv), wfq, None))
     if hasattr(lib, 'vittf_block_tail_fx') and os.environ.get('FX_LIB', '1') == '1':
         lib.vittf_block_tail_fx.restype = ctypes.c_int
         lib.vittf_block_tail_fx.argtypes = ARGS
@@ -53,6 +71,8 @@ def main():
         # main-phase-only builds stream 100 steps per tile: the main steps of the packed stream
         w = wfx[12:].contiguous() if int(re.match(r'\d+', v).group(0)) & 1 else wfx
         fns.append((v, f, w, so))
+        if not int(re.match(r'\d+', v).group(0)) & 1 and hasattr(so, 'vittf_block_tail_qkv'):
+            fns.append((v + 'q', q_entry(so.vittf_block_tail_qkv), wfq, so))
 
     def run(f, w):
         rc = f(hh.data_ptr(), w.data_ptr(), b2.data_ptr(), lg.data_ptr(), lb.data_ptr(), b1.data_ptr(), b2.data_ptr(), x.data_ptr(),
@@ -75,7 +95,7 @@ def main():
             ms = a.elapsed_time(b) / 10
             print(f'round {rnd} {v:>12s}: {ms:.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s (of the whole tail)', flush=True)
             if so is not None and int(re.match(r'\d+', v).group(0)) & 16 and rnd == 0:
-                stamps(so, v)
+                stamps(so, v)      # (the stamps of the launch that ran last: this entry's)
 
 
 def stamps(so, v):

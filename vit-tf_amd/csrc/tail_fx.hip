@@ -42,6 +42,10 @@ constexpr int MSTEPS = 2 * UNITS + LAG;      // main steps of a row tile
 #ifndef FX_NSLOT
 #define FX_NSLOT 4
 #endif
+#ifndef FX_STAGGER_PHASES      // start offsets between the workgroups (see the kernel): phases x sleeps x 8128 cycles
+#define FX_STAGGER_PHASES 0
+#define FX_STAGGER_SLEEPS 0
+#endif
 // timing-only builds (tools/fx_variants.sh; never in libvittf.so): 1 = main phase only (no tile boundary), 2 = no GELU
 // arithmetic, 4 = no LDS-DMA inside the steps, 8 = no fragment refills, 16 = stamps, 32 = steps without their barrier,
 // 64 = no raised priority for the F waves
@@ -775,8 +779,12 @@ __global__ __launch_bounds__(512, 1) void tail_fx_kernel(const unsigned short* _
                                                          const float* __restrict__ ln_b, float ln_eps,
                                                          unsigned short* __restrict__ hout, int ntiles,
                                                          unsigned* __restrict__ tile_ctr, const float* __restrict__ qkv_b,
-                                                         unsigned short* __restrict__ qkv_out) {
+                                                         unsigned short* __restrict__ qkv_out, int stagger_phases, int stagger_sleeps) {
   __shared__ __attribute__((aligned(16))) char smem[QKV ? LDSQ_BYTES : LDS_BYTES];
+  // Start offsets between the workgroups: the boundary of a tile is where ALL of its memory traffic happens (rows in, rows out:
+  // 0.6 - 1 MB per workgroup), the main phase has none; workgroups that start together stay in lockstep and hit HBM together.
+  // Workgroup b waits (b mod phases) x sleeps x 8128 cycles before it takes its first tile (the tile counter balances the rest).
+  for (int i = (int)(blockIdx.x % (unsigned)(stagger_phases > 0 ? stagger_phases : 1)) * stagger_sleeps; i > 0; --i) __builtin_amdgcn_s_sleep(127);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if constexpr (QKV) {
@@ -863,10 +871,16 @@ static int tail_fx_launch(bool qkv, const void* attn_out, const void* w_packed, 
   hipStream_t st = (hipStream_t)stream;
   unsigned* ctr = (unsigned*)tile_counter;
   if (hipMemsetAsync(ctr, 0, sizeof(unsigned), st) != hipSuccess) return VITTF_ERR_LAUNCH;
+  int phases = FX_STAGGER_PHASES, sleeps = FX_STAGGER_SLEEPS;
+#ifdef FX_STANDALONE
+  if (const char* e = getenv("VITTF_FX_PHASES")) phases = atoi(e);
+  if (const char* e = getenv("VITTF_FX_SLEEPS")) sleeps = atoi(e);
+#endif
+  if (tiles < 4 * (int64_t)grid) phases = 0;      // (short launches: nothing to spread)
 #define FX_LAUNCH(DTV, QV)                                                                                           \
   hipLaunchKernelGGL((tail_fx_kernel<DTV, QV>), dim3(grid), dim3(512), 0, st, (const unsigned short*)attn_out,       \
                      (const unsigned short*)w_packed, proj_b, ln2_g, ln2_b, b1, b2, x, rows, ln_g, ln_b, ln_eps,     \
-                     (unsigned short*)h_out, (int)tiles, ctr, qkv_b, (unsigned short*)qkv_out)
+                     (unsigned short*)h_out, (int)tiles, ctr, qkv_b, (unsigned short*)qkv_out, phases, sleeps)
   if (dtype == VITTF_BF16) { if (qkv) FX_LAUNCH(VITTF_BF16, true); else FX_LAUNCH(VITTF_BF16, false); }
   else if (dtype == VITTF_FP16) { if (qkv) FX_LAUNCH(VITTF_FP16, true); else FX_LAUNCH(VITTF_FP16, false); }
   else return VITTF_ERR_INVALID_ARG;
