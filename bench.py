@@ -112,7 +112,8 @@ def query_voxels(label, n=N_QUERIES):
 KERNEL_SOURCES = {     # what a kernel's code object is built from: its source, the shared headers and the Makefile's flags
     'attention': ('attention_pp64.hip', 'attn_common.h', 'vittf_common.h', 'Makefile'),
     'similarity': ('sim_mfma.hip', 'similarity.hip', 'vittf_common.h', 'Makefile'),
-    'block_tail': ('mlp.hip', 'vittf_common.h', 'Makefile'),
+    'block_tail': ('tail_fx.hip', 'vittf_common.h', 'Makefile'),
+    'gemm_qkv': ('gemm_as.hip', 'vittf_common.h', 'Makefile'),
 }
 
 
@@ -280,30 +281,6 @@ def main():
     vt._lib.profiler_enable(False)
     elapsed = max_over_ranks(elapsed)
 
-    # the same K steps once more with two batches in flight on two streams (outside the timed region, informative): the
-    # HBM-bound GEMM epilogues of one batch run under the attention of another; per-kernel durations stretch then, which
-    # is why the contract line above is measured with one lane
-    overlap = None
-    if os.environ.get('VITTF_BENCH_OVERLAP', '1') == '1':
-        lanes_before = vt.extract.STREAM_LANES
-        vt.extract.STREAM_LANES = 2
-        try:
-            step()
-            torch.cuda.synchronize()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            barrier()
-            el2 = time.perf_counter() - t1
-        finally:
-            vt.extract.STREAM_LANES = lanes_before
-        el2 = max_over_ranks(el2)
-        overlap = {'stream_lanes': 2, 'value': round(args.steps * total_slices / el2, 2), 'unit': 'slices/s',
-                   'ms_per_step': round(el2 / args.steps * 1e3, 2),
-                   'note': 'VITTF_STREAM_LANES=2, same steps, measured after the timed region; not the contract value'}
-
     # the reference's own bracket (infer.py:324 -> 336) also contains what bench.py's contract keeps OUT of the timed region:
     # the volume's way to the device (host fp16 -> HBM, infer.py:177 `.to(dev)`), `vol.float()` (:137) and the global
     # min / max (:155).  Measured here for the same K steps, behind the timed region: every step starts from the HOST volume.
@@ -386,10 +363,10 @@ def main():
         if prof['gemm_proj'][1] == 0:   # ... block tail: with the attention projection in front of them
             flop_slice['mlp'] += flop_slice.pop('gemm_proj')
     flops = {k: v * slices_done for k, v in flop_slice.items()}
-    kernels = {'attention': f"{vt._lib.kernel_name('attention')}<{args.dtype}>", 'gemm_qkv': f'gemm_ws_kernel<{args.dtype}, qkv>',
-               'gemm_fc1': f'gemm_ws_kernel<{args.dtype}, fc1+gelu>', 'gemm_proj': f'gemm_rows_kernel<{args.dtype}, proj+ln>',
+    kernels = {'attention': f"{vt._lib.kernel_name('attention')}<{args.dtype}>", 'gemm_qkv': f"{vt._lib.kernel_name('gemm_qkv') or 'gemm_kernel'}<{args.dtype}, qkv>",
+               'gemm_fc1': f'gemm_kernel<{args.dtype}, fc1+gelu>', 'gemm_proj': f'gemm_rows_kernel<{args.dtype}, proj+ln>',
                'gemm_fc2': f'gemm_rows_kernel<{args.dtype}, fc2+ln>', 'gemm': f'gemm_kernel<{args.dtype}, kfeat>',
-               'mlp': f"{vt._lib.kernel_name('mlp') or 'mlp_kernel'}<{args.dtype}>", 'patch_embed': 'patch_embed_kernel', 'layernorm': 'layernorm_kernel'}
+               'mlp': f"{vt._lib.kernel_name('mlp') or 'tail_fx_kernel'}<{args.dtype}>", 'patch_embed': 'patch_embed_kernel', 'layernorm': 'layernorm_kernel'}
     # the kernel with the largest share of the step
     dom = max((k for k in prof if k in flops), key=lambda k: prof[k][0])
     dom_ms, dom_launches = prof[dom]
@@ -411,7 +388,7 @@ def main():
         'whole_vit_tflops': round(sum(flops.values()) / (vit_ms * 1e-3) / 1e12, 2) if vit_ms > 0 else 0.0,
     }
 
-    # the second-largest kernel since round 3: everything behind the attention of a block in one launch (csrc/mlp.hip)
+    # the second-largest kernel since round 3: everything behind the attention of a block in one launch (csrc/tail_fx.hip)
     roofline_tail = None
     if prof['mlp'][1] > 0 and prof['mlp'][0] > 0:
         t_ms, t_n = prof['mlp']
@@ -455,7 +432,6 @@ def main():
                            'note': 'ms: the reference API (uint8 maps returned as CPU tensors: ms - ms_maps_on_device is the D2H copy of '
                                    'maps_bytes_to_host over PCIe); ms_maps_on_device: keep_on_device=True'},
         }
-        out['two_lane_overlap'] = overlap
         out['e2e_incl_upload'] = e2e
         if world == 1 and args.cpu_slices > 0:
             out['cpu_baseline'] = cpu_baseline(sd, vol, args.cpu_slices, im_sz, args.arch, feats.cpu(), ann, tuple(dvol.shape))

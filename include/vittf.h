@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITTF_ABI_VERSION 5
+#define VITTF_ABI_VERSION 6
 
 typedef enum vittf_status {
   VITTF_OK = 0,
@@ -60,7 +60,16 @@ typedef struct vittf_vit_config {
   float   ln_eps;      /* 1e-6 */
   int32_t attention_fp8; /* 0: 16-bit attention (default).  1: the fp8 (e4m3) block-scaled MFMA attention path of BASELINE
                             configs[3] (vittf_attention_fp8): 3-mantissa-bit operands, ~3e-2 on the features -- opt-in */
+  int32_t flags;       /* 0 = the measured path.  Bits select the slower alternatives the parity tests also run (ABI 6: they
+                            were environment variables latched inside the library before -- the library reads no environment
+                            on this path any more): */
 } vittf_vit_config;
+enum {
+  VITTF_CFG_SEPARATE_LN = 1,       /* every LayerNorm as its own launch instead of riding on the kernel in front of it */
+  VITTF_CFG_UNSCALED_Q = 2,        /* q as the model produces it + the online-maximum attention kernel (vittf_attention(.., 0)) */
+  VITTF_CFG_FP8_HEAD_SCALES = 4    /* fp8 attention with one scale per (slice, head) (absmax + quantise launches) instead of row scales */
+};
+#define VITTF_TAIL_STEPS 112       /* 24 KB steps of one block in vittf_vit_weights.tail_packed */
 
 /* All weights live in HBM for the lifetime of the engine (about 43 MB for ViT-S).  Per-layer tensors
  * are stacked along a leading L dimension.  "h16" matrices are row-major [out][in] exactly like the
@@ -77,14 +86,12 @@ typedef struct vittf_vit_weights {
   const float* fc1_b;    /* [L][4D] */
   const void*  fc2_w;    /* h16 [L][D][4D]   blocks.i.mlp.fc2.weight */
   const float* fc2_b;    /* [L][D] */
-  const void*  mlp_packed; /* h16 [L][96][12288] or NULL: fc1_w and fc2_w of every block as the stream of 24 KB LDS images the
-                            fused MLP kernel consumes (vittf_mlp_fused; packing: vit-tf_amd/weights.py pack_mlp_weights);
-                            when non-NULL and D == 384 the engine runs fc1 -> GELU -> fc2 -> residual -> next LayerNorm as
-                            one launch instead of two GEMMs */
-  const void*  tail_packed; /* h16 [L][108][12288] or NULL: proj_w, fc1_w and fc2_w of every block as the stream of the
-                            block-tail kernel (vittf_block_tail; weights.py pack_block_tail_weights); when non-NULL and
-                            D == 384 the engine runs everything behind the attention of a block -- proj, residual, norm2,
-                            MLP, residual, the next block's norm1 -- as one launch (takes precedence over mlp_packed) */
+  const void*  tail_packed; /* h16 [L][112][12288] or NULL: proj_w, fc1_w and fc2_w of every block as the weight stream of the
+                            block-tail kernel (vittf_block_tail; packing: vit-tf_amd/weights.py pack_block_tail_weights); when
+                            non-NULL and D == 384 the engine runs everything behind the attention of a block -- proj, residual,
+                            norm2, MLP, residual, the next block's norm1 -- as one launch */
+  const void*  qkv_packed; /* h16 [L][3D/32][12288] or NULL: qkv_w as the 24 KB LDS images of vittf_gemm_as (weights.py
+                            pack_row_images); when non-NULL and D == 384 the qkv projection runs on the activation-stationary kernel */
   const float* ln1_g;    /* [L][D] */
   const float* ln1_b;    /* [L][D] */
   const float* ln2_g;    /* [L][D] */
@@ -191,35 +198,29 @@ int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64
 int vittf_gemm_residual_ln(const void* a, const void* w, const float* bias, float* x, int64_t rows, int32_t n, int32_t k,
                            int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h, void* stream);
 
-/* LayerNorm fused into the weight-stationary GEMM (K = 384 only): out = epilogue(LayerNorm(x; g, b, eps) . W^T + bias),
- * x fp32 [rows][384] (the residual stream), epilogue VITTF_EPI_BIAS / _BIAS_GELU / _BIAS_QKV, 16-bit out [rows][n],
- * n % 384 == 0.  Replaces norm1 + attn.qkv and norm2 + mlp.fc1 of a block without the 16-bit LayerNorm tensor ever
- * reaching HBM.  Other shapes: VITTF_ERR_INVALID_ARG (use vittf_layernorm + vittf_gemm). */
-int vittf_ln_gemm(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const void* w, const float* bias,
-                  void* out, int64_t rows, int32_t n, int32_t k, int32_t epilogue, int32_t dtype, void* stream);
-
-/* Fused MLP of one block for D == 384:  x[rows][D] (fp32) += fc2(gelu_erf(fc1(h) + b1)) + b2 without ever writing the
- * [rows][4D] hidden activation, and -- when ln_g / ln_b / h_out are given -- h_out[rows][D] (h16) = LayerNorm(x_new; ln_g,
- * ln_b, ln_eps) on the way out (the next block's norm1).  h: h16 [rows][D] (LayerNorm2 output); w_packed: h16 [96][12288], one
- * block of vittf_vit_weights.mlp_packed.  Same result as vittf_gemm(BIAS_GELU) + vittf_gemm_residual_ln up to the fp32
- * summation order of fc2 (the hidden activation is identical: both round it once to h16).
- * tile_counter: vittf_block_tail_workspace_bytes() bytes of caller-owned device memory, 4-byte aligned, private to this
- * call until it has finished on `stream` (the persistent workgroups hand out 128-row tiles through it; the call zeroes it
- * on `stream` itself).  Calls that may run concurrently -- two streams -- need one counter each. */
-int vittf_mlp_fused(const void* h, const void* w_packed, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
-                    int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* tile_counter,
-                    void* stream);
+/* The K = 384 linears with a wide 16-bit output (Attention.qkv of ViT-S) with the ACTIVATIONS stationary: a wave keeps its 32 rows
+ * as 24 MFMA operands and the weights stream through LDS, so every activation byte is read once.  out = epilogue(a . w^T + bias),
+ * epilogue VITTF_EPI_BIAS or VITTF_EPI_BIAS_QKV; k == 384; n a multiple of 64, at most 1536 (a multiple of 96 for _QKV).
+ * w_packed: h16 [n / 32][12288], the 24 KB images of weights.py pack_row_images (image u = rows 32 u .. + 31 of w in the LDS
+ * tile layout).  Same bits as vittf_gemm on the same operands.  tile_counter: vittf_gemm_as_workspace_bytes() bytes of
+ * caller-owned device memory, 4-byte aligned, private to this call until it has finished on `stream` (256-row tiles are handed
+ * out through it; the call zeroes it on `stream` itself); concurrent calls need one each. */
+size_t vittf_gemm_as_workspace_bytes(void);
+int vittf_gemm_as(const void* a, const void* w_packed, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
+                  int32_t epilogue, int32_t dtype, void* tile_counter, void* stream);
 
 /* Everything behind the attention of one block for D == 384, in one launch:
  *   x' = x + attn_out . Wp^T + proj_b ;  x_new = x' + fc2(gelu_erf(fc1(LayerNorm(x'; ln2)) + b1)) + b2 ;  x := x_new ;
- *   h_out = LayerNorm(x_new; ln_g, ln_b)  (the next block's norm1; optional as in vittf_mlp_fused).
+ *   h_out = LayerNorm(x_new; ln_g, ln_b)  (the next block's norm1; optional: ln_g, ln_b, h_out all NULL leaves it out).
  * Replaces Attention.proj + the two residual adds + norm2 + Mlp.forward of the upstream DINO block (reached through
- * model(...), infer.py:177).  attn_out: h16 [rows][D] (vittf_attention's output); w_packed: h16 [108][12288], one block of
- * vittf_vit_weights.tail_packed.  The fp32 residual rows are read once and written once, and neither x' nor norm2's output
- * nor the hidden activation reaches HBM.  Same result as vittf_gemm_residual_ln (proj) + vittf_mlp_fused up to fp32
- * summation order.  attn_out, w_packed, x and h_out must be 16-byte aligned (VITTF_ERR_INVALID_ARG otherwise); D != 384:
- * VITTF_ERR_INVALID_ARG (use the GEMM entries).  tile_counter: as for vittf_mlp_fused (caller-owned, one per concurrent
- * call; inside vittf_vit_k_features it lives in the engine workspace). */
+ * model(...), infer.py:177).  attn_out: h16 [rows][D] (vittf_attention's output); w_packed: h16 [VITTF_TAIL_STEPS][12288], one
+ * block of vittf_vit_weights.tail_packed.  The fp32 residual rows are read once and written once, and neither x' nor norm2's
+ * output nor the hidden activation reaches HBM.  Same result as vittf_gemm_residual_ln (proj) + vittf_gemm(BIAS_GELU) +
+ * vittf_gemm_residual_ln (fc2) up to fp32 summation order.  attn_out, w_packed, x and h_out must be 16-byte aligned
+ * (VITTF_ERR_INVALID_ARG otherwise); D != 384: VITTF_ERR_INVALID_ARG (use the GEMM entries).  tile_counter:
+ * vittf_block_tail_workspace_bytes() bytes of caller-owned device memory, 4-byte aligned, private to this call until it has
+ * finished on `stream` (the persistent workgroups hand out 128-row tiles through it; the call zeroes it on `stream` itself;
+ * concurrent calls -- two streams -- need one each; inside vittf_vit_k_features it lives in the engine workspace). */
 size_t vittf_block_tail_workspace_bytes(void);
 int vittf_block_tail(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g, const float* ln2_b,
                      const float* b1, const float* b2, float* x, int64_t rows, int32_t d, int32_t dtype, const float* ln_g,
@@ -229,7 +230,8 @@ int vittf_block_tail(const void* attn_out, const void* w_packed, const float* pr
  * qkv h16 [batch*tokens][3D] with columns [q | k | v], heads of 64 concatenated inside each third
  * (layout of Attention.qkv's output); out h16 [batch*tokens][D] = softmax(q k^T / 8) v per head.
  * q_prescaled = 0: q as the model produces it.  q_prescaled = 1: q already multiplied by log2(e)/8
- * (VITTF_EPI_BIAS_QKV) -- same result, computed by the faster lazy-maximum kernel the engine uses. */
+ * (VITTF_EPI_BIAS_QKV) -- same result, computed by the faster kernel the engine uses (two 32-row query blocks per wave taking
+ * turns, lazy running maximum). */
 int vittf_attention(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype,
                     int32_t q_prescaled, void* stream);
 

@@ -85,6 +85,43 @@ def test_gemm_residual(gpu, dt, rows, n, k):
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('rows,n,epi', [(1, 1152, 'qkv'), (255, 1152, 'qkv'), (4097, 1152, 'qkv'), (256 * 300 + 77, 1152, 'qkv'),
+                                        (4097, 384, 'bias'), (1000, 1536, 'bias')])
+def test_gemm_as_same_bits_as_tiled_kernel(gpu, dt, rows, n, epi):
+    """The activation-stationary K = 384 GEMM (csrc/gemm_as.hip: a wave keeps its rows as 24 B fragments, the weights stream
+    through the ring) forms every output as vittf_gemm's kernels do -- one ascending-k chain from zero, then
+    (acc + bias) * scale -- so the outputs are bit-equal; more row tiles than workgroups (the stream wraps, tiles come from the
+    counter), a partial last tile, guard rows untouched; against fp64 as well."""
+    lib = _lib.load()
+    k = 384
+    g = gen(rows + n)
+    a = torch.randn(rows, k, generator=g).to(TDT[dt]).to(gpu)
+    w = (1.3 * torch.randn(n, k, generator=g) / k ** 0.5).to(TDT[dt]).to(gpu)
+    bias = (0.3 * torch.randn(n, generator=g)).to(gpu)
+    e = _lib.EPI_BIAS_QKV if epi == 'qkv' else _lib.EPI_BIAS
+    ref = torch.full((rows + GUARD_ROWS, n), 5.0, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_gemm(_lib.ptr(a), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(ref), rows, n, k, e, 0, _lib.DTYPES[dt], _lib.stream_ptr()))
+    wpk = vt.weights.pack_row_images(w[None])[0]
+    assert wpk.shape == (n // 32, 12288)
+    out = torch.full((rows + GUARD_ROWS, n), 5.0, dtype=TDT[dt], device=gpu)
+    ctr = torch.full((1,), 777, dtype=torch.int32, device=gpu)
+    assert lib.vittf_gemm_as_workspace_bytes() <= 4
+    _lib.check(lib.vittf_gemm_as(_lib.ptr(a), _lib.ptr(wpk), _lib.ptr(bias), _lib.ptr(out), rows, n, k, e, _lib.DTYPES[dt], _lib.ptr(ctr),
+                                 _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert (out[rows:].float() == 5.0).all(), 'wrote past the last row'
+    assert torch.equal(out[:rows], ref[:rows]), f'{int((out[:rows] != ref[:rows]).sum())} values differ from vittf_gemm'
+    want = a.double() @ w.double().t() + bias.double()
+    if epi == 'qkv':
+        want[:, :n // 3] *= QSCALE
+    assert rel_fro(out[:rows].double(), want) <= EPS[dt]
+    # refused: other k, odd column counts, a missing counter
+    assert lib.vittf_gemm_as(_lib.ptr(a), _lib.ptr(wpk), _lib.ptr(bias), _lib.ptr(out), rows, n, 768, e, _lib.DTYPES[dt], _lib.ptr(ctr), _lib.stream_ptr()) == -1
+    assert lib.vittf_gemm_as(_lib.ptr(a), _lib.ptr(wpk), _lib.ptr(bias), _lib.ptr(out), rows, n + 32, k, _lib.EPI_BIAS, _lib.DTYPES[dt], _lib.ptr(ctr), _lib.stream_ptr()) == -1
+    assert lib.vittf_gemm_as(_lib.ptr(a), _lib.ptr(wpk), _lib.ptr(bias), _lib.ptr(out), rows, n, k, e, _lib.DTYPES[dt], None, _lib.stream_ptr()) == -1
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 def test_gemm_kfeat_drops_cls_rows(gpu, dt):
     lib = _lib.load()
     tokens, batch, n, k = 17, 9, 128, 128
@@ -116,62 +153,12 @@ GUARD_ROWS = 32
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-@pytest.mark.parametrize('rows,with_ln', [(1, True), (130, True), (4097, False), (4097, True), (128 * 300 + 77, True)])
-def test_mlp_fused(gpu, dt, rows, with_ln):
-    """x += fc2(gelu(fc1(h))) with the hidden activation kept in registers (+ the LayerNorm of the new rows), against fp64
-    (hidden rounded once to the 16-bit type, as both the fused and the two-GEMM path do) and against the two-GEMM path
-    itself; 300 row tiles + a partial one: more tiles than persistent workgroups, the weight stream wraps many times."""
-    lib = _lib.load()
-    d = 384
-    g = gen(rows)
-    h = torch.randn(rows, d, generator=g).to(TDT[dt])
-    w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt])
-    b1 = 0.3 * torch.randn(4 * d, generator=g)
-    w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
-    b2 = 0.3 * torch.randn(d, generator=g)
-    lg, lb = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
-    x0 = torch.randn(rows + GUARD_ROWS, d, generator=g) * 3
-    ctr = torch.full((1,), 12345, dtype=torch.int32, device=gpu)      # caller-owned tile counter (zeroed by the call itself)
-    assert lib.vittf_block_tail_workspace_bytes() <= ctr.numel() * 4
-    hd, w1d, b1d, w2d, b2d, lgd, lbd = (t.to(gpu) for t in (h, w1, b1, w2, b2, lg, lb))
-    hid = F.gelu(hd.double() @ w1d.double().t() + b1d.double()).to(TDT[dt]).double()
-    ref = (x0[:rows].to(gpu).double() + hid @ w2d.double().t() + b2d.double()).cpu()
-    wpk = vt.weights.pack_mlp_weights(w1d[None], w2d[None])[0].contiguous()
-    assert wpk.shape == (96, 12288)
-    xd = x0.to(gpu)
-    hn = torch.full((rows + GUARD_ROWS, d), 7.0, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_mlp_fused(_lib.ptr(hd), _lib.ptr(wpk), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(xd), rows, d, _lib.DTYPES[dt],
-                                   _lib.ptr(lgd) if with_ln else None, _lib.ptr(lbd) if with_ln else None, 1e-6,
-                                   _lib.ptr(hn) if with_ln else None, _lib.ptr(ctr), _lib.stream_ptr()))
-    got = xd.cpu().double()
-    assert torch.equal(got[rows:], x0[rows:].double()), 'wrote past the last row'
-    # a hidden unit whose fp32 pre-activation sits on a rounding boundary may round the other way than in fp64
-    assert ((got[:rows] - ref).abs() <= 3 * EPS[dt] + 1e-4).all()
-    assert rel_fro(got[:rows] - x0[:rows].double(), ref - x0[:rows].double()) <= EPS[dt] / 4
-    # the unfused path: fc1 + GELU GEMM, then fc2 + residual (+ LayerNorm) GEMM
-    gbuf = torch.zeros(rows, 4 * d, dtype=TDT[dt], device=gpu)
-    x2 = x0.to(gpu)
-    h2 = torch.zeros(rows, d, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_gemm(_lib.ptr(hd), _lib.ptr(w1d), _lib.ptr(b1d), _lib.ptr(gbuf), rows, 4 * d, d, _lib.EPI_BIAS_GELU, 0,
-                              _lib.DTYPES[dt], _lib.stream_ptr()))
-    _lib.check(lib.vittf_gemm_residual_ln(_lib.ptr(gbuf), _lib.ptr(w2d), _lib.ptr(b2d), _lib.ptr(x2), rows, d, 4 * d, _lib.DTYPES[dt],
-                                          _lib.ptr(lgd), _lib.ptr(lbd), 1e-6, _lib.ptr(h2), _lib.stream_ptr()))
-    assert torch.allclose(xd[:rows], x2[:rows], rtol=0, atol=2e-4 * float(ref.abs().max()))
-    if with_ln:
-        assert (hn[rows:].float() == 7.0).all(), 'wrote past the last row of h'
-        want = F.layer_norm(got[:rows], (d,), lg.double(), lb.double(), 1e-6)
-        assert ((hn[:rows].cpu().double() - want).abs() <= 2 * EPS[dt] * (1 + want.abs())).all()
-        assert torch.allclose(hn[:rows].float(), h2.float(), rtol=0, atol=4 * EPS[dt] * float(want.abs().max()))
-    assert lib.vittf_mlp_fused(_lib.ptr(hd), _lib.ptr(wpk), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(xd), rows, 768, _lib.DTYPES[dt],
-                               None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()) == -1
-
-
-@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('rows', [1, 130, 4097, 128 * 300 + 77])
 def test_block_tail(gpu, dt, rows):
-    """proj + residual + norm2 + MLP + residual + the next norm1 in one launch (vittf_block_tail) against fp64 (norm2's
-    output and the hidden activation rounded once to the 16-bit type, as every path does) and against the launches it
-    replaces (vittf_gemm_residual_ln for proj, vittf_mlp_fused)."""
+    """proj + residual + norm2 + MLP + residual + the next norm1 in one launch (vittf_block_tail, csrc/tail_fx.hip) against fp64
+    (norm2's output and the hidden activation rounded once to the 16-bit type, as every path does) and against the three GEMM
+    launches it replaces.  (Round 5: the role-split kernel was bit-equal to round 3's one-wave kernel on all of these shapes
+    before that kernel was removed: commit 89da172, profiles/r05b.)"""
     lib = _lib.load()
     d = 384
     g = gen(rows + 5)
@@ -193,7 +180,7 @@ def test_block_tail(gpu, dt, rows):
     hid = F.gelu(hn @ w1d.double().t() + b1d.double()).to(TDT[dt]).double()
     ref = (x1 + hid @ w2d.double().t() + b2d.double()).cpu()
     wpk = vt.weights.pack_block_tail_weights(wpd[None], w1d[None], w2d[None])[0].contiguous()
-    assert wpk.shape == (108, 12288)
+    assert wpk.shape == (112, 12288)
     xd = x0.to(gpu)
     hout = torch.full((rows + GUARD_ROWS, d), 7.0, dtype=TDT[dt], device=gpu)
     _lib.check(lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
@@ -207,15 +194,17 @@ def test_block_tail(gpu, dt, rows):
     assert ((got[:rows] - ref).abs() <= 6 * EPS[dt] + 1e-4).all()
     want = F.layer_norm(got[:rows], (d,), g1.double(), e1.double(), 1e-6)
     assert ((hout[:rows].cpu().double() - want).abs() <= 2 * EPS[dt] * (1 + want.abs())).all()
-    # the launches it replaces
+    # the launches it replaces: proj + residual + norm2, fc1 + GELU, fc2 + residual + the next norm1
     x2 = x0.to(gpu)
     h2 = torch.zeros(rows, d, dtype=TDT[dt], device=gpu)
     _lib.check(lib.vittf_gemm_residual_ln(_lib.ptr(ad), _lib.ptr(wpd), _lib.ptr(bpd), _lib.ptr(x2), rows, d, d, _lib.DTYPES[dt],
                                           _lib.ptr(g2d), _lib.ptr(e2d), 1e-6, _lib.ptr(h2), _lib.stream_ptr()))
-    mpk = vt.weights.pack_mlp_weights(w1d[None], w2d[None])[0].contiguous()
+    gbuf = torch.zeros(rows, 4 * d, dtype=TDT[dt], device=gpu)
+    _lib.check(lib.vittf_gemm(_lib.ptr(h2), _lib.ptr(w1d), _lib.ptr(b1d), _lib.ptr(gbuf), rows, 4 * d, d, _lib.EPI_BIAS_GELU, 0,
+                              _lib.DTYPES[dt], _lib.stream_ptr()))
     h3 = torch.zeros(rows, d, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_mlp_fused(_lib.ptr(h2), _lib.ptr(mpk), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(x2), rows, d, _lib.DTYPES[dt],
-                                   _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h3), _lib.ptr(ctr), _lib.stream_ptr()))
+    _lib.check(lib.vittf_gemm_residual_ln(_lib.ptr(gbuf), _lib.ptr(w2d), _lib.ptr(b2d), _lib.ptr(x2), rows, d, 4 * d, _lib.DTYPES[dt],
+                                          _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h3), _lib.stream_ptr()))
     assert rel_fro(xd[:rows].double() - x0[:rows].to(gpu).double(), x2[:rows].double() - x0[:rows].to(gpu).double()) <= EPS[dt] / 2
     assert rel_fro(hout[:rows].float(), h3.float()) <= 2 * EPS[dt]
     # misaligned rows are refused, not mis-read (every access is 16 bytes wide)
@@ -228,100 +217,6 @@ def test_block_tail(gpu, dt, rows):
     assert torch.equal(x3, xd)
     assert lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wpk), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
                                 _lib.ptr(xd), rows, 768, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()) == -1
-
-
-@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-@pytest.mark.parametrize('rows', [1, 130, 4097, 128 * 300 + 77])
-def test_block_tail_fx_same_bits_as_one_wave_kernel(gpu, dt, rows):
-    """The role-split block tail (csrc/tail_fx.hip: X waves hold the fp32 rows, F waves the 16-bit rows) performs, per
-    accumulator, the SAME sequence of operations as the one-wave-per-SIMD kernel of csrc/mlp.hip (projection k steps in
-    ascending order, + residual, the same LayerNorm passes, fc1 over ascending k, the same GELU pieces, fc2 over ascending
-    hidden units): residual rows and the next LayerNorm's output must be bit-equal, guard rows untouched."""
-    lib = _lib.load()
-    d = 384
-    g = gen(rows + 11)
-    a = torch.randn(rows, d, generator=g).to(TDT[dt])
-    wp = (torch.randn(d, d, generator=g) / d ** 0.5).to(TDT[dt])
-    w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt])
-    w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
-    bp, b1, b2 = (0.3 * torch.randn(n, generator=g) for n in (d, 4 * d, d))
-    g2, e2 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
-    g1, e1 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
-    x0 = torch.randn(rows + GUARD_ROWS, d, generator=g) * 3
-    ctr = torch.zeros(1, dtype=torch.int32, device=gpu)
-    ad, wpd, bpd, w1d, b1d, w2d, b2d, g2d, e2d, g1d, e1d = (t.to(gpu) for t in (a, wp, bp, w1, b1, w2, b2, g2, e2, g1, e1))
-    wold = vt.weights.pack_block_tail_weights(wpd[None], w1d[None], w2d[None])[0].contiguous()
-    wfx = vt.weights.pack_tail_fx_weights(wpd[None], w1d[None], w2d[None])[0].contiguous()
-    assert wfx.shape == (112, 12288)
-    outs = []
-    for fn, w in ((lib.vittf_block_tail, wold), (lib.vittf_block_tail_fx, wfx)):
-        xd = x0.to(gpu)
-        hout = torch.full((rows + GUARD_ROWS, d), 7.0, dtype=TDT[dt], device=gpu)
-        _lib.check(fn(_lib.ptr(ad), _lib.ptr(w), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d), _lib.ptr(xd), rows, d,
-                      _lib.DTYPES[dt], _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(hout), _lib.ptr(ctr), _lib.stream_ptr()))
-        torch.cuda.synchronize()
-        outs.append((xd, hout))
-    (x_old, h_old), (x_new, h_new) = outs
-    assert torch.equal(x_new[rows:].cpu(), x0[rows:]), 'wrote past the last row'
-    assert (h_new[rows:].float() == 7.0).all(), 'wrote past the last row of h'
-    assert torch.equal(x_new, x_old), f'{int((x_new != x_old).sum())} residual values differ'
-    assert torch.equal(h_new, h_old)
-    # without the LayerNorm on the way out: the same residual rows, nothing else written
-    x3 = x0.to(gpu)
-    _lib.check(lib.vittf_block_tail_fx(_lib.ptr(ad), _lib.ptr(wfx), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
-                                       _lib.ptr(x3), rows, d, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()))
-    assert torch.equal(x3, x_new)
-    assert lib.vittf_block_tail_fx(_lib.ptr(ad), _lib.ptr(wfx), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
-                                   _lib.ptr(x3), rows, 768, _lib.DTYPES[dt], None, None, 1e-6, None, _lib.ptr(ctr), _lib.stream_ptr()) == -1
-
-
-@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-@pytest.mark.parametrize('rows', [1, 130, 4097, 128 * 300 + 77])
-def test_block_tail_qkv_same_bits_as_separate_launches(gpu, dt, rows):
-    """vittf_block_tail_qkv = the block tail + the NEXT block's qkv projection of the new rows in one launch: residual rows
-    and LayerNorm output bit-equal to vittf_block_tail, the qkv rows bit-equal to the stand-alone GEMM on that LayerNorm
-    output (vittf_gemm, VITTF_EPI_BIAS_QKV: q third pre-scaled by log2(e) / 8); guard rows of all three outputs untouched."""
-    lib = _lib.load()
-    d = 384
-    g = gen(rows + 23)
-    a = torch.randn(rows, d, generator=g).to(TDT[dt])
-    wp = (torch.randn(d, d, generator=g) / d ** 0.5).to(TDT[dt])
-    w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt])
-    w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt])
-    wq = (1.3 * torch.randn(3 * d, d, generator=g) / d ** 0.5).to(TDT[dt])
-    bp, b1, b2, bq = (0.3 * torch.randn(n, generator=g) for n in (d, 4 * d, d, 3 * d))
-    g2, e2 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
-    g1, e1 = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
-    x0 = torch.randn(rows + GUARD_ROWS, d, generator=g) * 3
-    ctr = torch.zeros(1, dtype=torch.int32, device=gpu)
-    ad, wpd, bpd, w1d, b1d, w2d, b2d, g2d, e2d, g1d, e1d, wqd, bqd = (t.to(gpu) for t in (a, wp, bp, w1, b1, w2, b2, g2, e2, g1, e1, wq, bq))
-    wold = vt.weights.pack_block_tail_weights(wpd[None], w1d[None], w2d[None])[0].contiguous()
-    wfq = vt.weights.pack_tail_fx_qkv_weights(wpd[None], w1d[None], w2d[None], wqd[None])[0].contiguous()
-    assert wfq.shape == (172, 12288)
-    x_old = x0.to(gpu)
-    h_old = torch.full((rows + GUARD_ROWS, d), 7.0, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_block_tail(_lib.ptr(ad), _lib.ptr(wold), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
-                                    _lib.ptr(x_old), rows, d, _lib.DTYPES[dt], _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h_old), _lib.ptr(ctr),
-                                    _lib.stream_ptr()))
-    q_old = torch.full((rows + GUARD_ROWS, 3 * d), 5.0, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_gemm(_lib.ptr(h_old), _lib.ptr(wqd), _lib.ptr(bqd), _lib.ptr(q_old), rows, 3 * d, d, _lib.EPI_BIAS_QKV, 0, _lib.DTYPES[dt],
-                              _lib.stream_ptr()))
-    x_new = x0.to(gpu)
-    h_new = torch.full((rows + GUARD_ROWS, d), 7.0, dtype=TDT[dt], device=gpu)
-    q_new = torch.full((rows + GUARD_ROWS, 3 * d), 5.0, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_block_tail_qkv(_lib.ptr(ad), _lib.ptr(wfq), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
-                                        _lib.ptr(x_new), rows, d, _lib.DTYPES[dt], _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h_new),
-                                        _lib.ptr(bqd), _lib.ptr(q_new), _lib.ptr(ctr), _lib.stream_ptr()))
-    torch.cuda.synchronize()
-    assert torch.equal(x_new[rows:].cpu(), x0[rows:]), 'wrote past the last row of x'
-    assert (h_new[rows:].float() == 7.0).all() and (q_new[rows:].float() == 5.0).all(), 'wrote past the last row of h / qkv'
-    assert torch.equal(x_new, x_old), f'{int((x_new != x_old).sum())} residual values differ'
-    assert torch.equal(h_new, h_old)
-    assert torch.equal(q_new[:rows], q_old[:rows]), f'{int((q_new[:rows] != q_old[:rows]).sum())} qkv values differ'
-    # arguments the entry refuses
-    assert lib.vittf_block_tail_qkv(_lib.ptr(ad), _lib.ptr(wfq), _lib.ptr(bpd), _lib.ptr(g2d), _lib.ptr(e2d), _lib.ptr(b1d), _lib.ptr(b2d),
-                                    _lib.ptr(x_new), rows, d, _lib.DTYPES[dt], _lib.ptr(g1d), _lib.ptr(e1d), 1e-6, _lib.ptr(h_new),
-                                    None, _lib.ptr(q_new), _lib.ptr(ctr), _lib.stream_ptr()) == -1
 
 
 def test_block_tail_two_streams_caller_owned_counters(gpu):
@@ -390,31 +285,21 @@ def _attn_ref(qkv, batch, tokens, heads, pre=0):
     return (att.softmax(-1) @ v).transpose(1, 2).reshape(batch * tokens, d)
 
 
-# q as produced | pre-scaled q: two 32-row blocks per wave taking turns (default) | pre-scaled q: the round-1 lazy-maximum kernel
-ATTN_VARIANTS = ['plain', 'pingpong', 'lazy']
+# q as produced (the online-maximum kernel) | pre-scaled q: two 32-row blocks per wave taking turns (what the engine runs)
+ATTN_VARIANTS = ['plain', 'pingpong']
 
 
 def _attn_variant(variant):
-    """-> q_prescaled flag; selects the kernel behind vittf_attention(q_prescaled = 1) through its (per-call) switch."""
-    import os
-    code = {'lazy': '0'}.get(variant)
-    if code is None:                         # 'plain' (its own kernel) and 'pingpong' (the default behind pre-scaled q)
-        os.environ.pop('VITTF_ATTN_PIPE', None)
-    else:
-        os.environ['VITTF_ATTN_PIPE'] = code
+    """-> the q_prescaled flag of vittf_attention, which selects the kernel."""
     return 0 if variant == 'plain' else 1
 
 
 def _run_attn(gpu, qkv, batch, tokens, heads, dt, pre=0, pad_rows=2):
-    import os
     lib = _lib.load()
     qd = qkv.to(gpu)
     out = torch.full((batch * tokens + pad_rows, heads * 64), 7.0, dtype=TDT[dt], device=gpu)
-    try:
-        _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], pre, _lib.stream_ptr()))
-        torch.cuda.synchronize()
-    finally:
-        os.environ.pop('VITTF_ATTN_PIPE', None)
+    _lib.check(lib.vittf_attention(_lib.ptr(qd), _lib.ptr(out), batch, tokens, heads, _lib.DTYPES[dt], pre, _lib.stream_ptr()))
+    torch.cuda.synchronize()
     got = out.float().cpu().double()
     assert (got[batch * tokens:] == 7.0).all(), 'wrote past the last row'
     return got[:batch * tokens]
@@ -981,50 +866,8 @@ def test_similarity_mfma_768_features(gpu, monkeypatch, grid, counts):
 
 
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
-@pytest.mark.parametrize('rows,n,epi', [(1, 384, 'bias'), (77, 1152, 'bias'), (4097, 1536, 'gelu'), (19205, 1152, 'bias')])
-def test_ln_gemm_fused(gpu, dt, rows, n, epi):
-    """LayerNorm inside the weight-stationary GEMM's loader against LayerNorm (fp64) -> rounding to the operand type ->
-    GEMM (fp64), and against the two separate kernels."""
-    lib = _lib.load()
-    g = gen(rows + n)
-    x = torch.randn(rows, 384, generator=g) * 2.0 + 0.3 * torch.randn(1, 384, generator=g)
-    lg, lb = 1.0 + 0.2 * torch.randn(384, generator=g), 0.1 * torch.randn(384, generator=g)
-    w = (torch.randn(n, 384, generator=g) / 384 ** 0.5).to(TDT[dt])
-    bias = 0.2 * torch.randn(n, generator=g)
-    code = _lib.EPI_BIAS if epi == 'bias' else _lib.EPI_BIAS_GELU
-    xd, gd, bd, wd, biasd = x.to(gpu), lg.to(gpu), lb.to(gpu), w.to(gpu), bias.to(gpu)
-    out = torch.full((rows + 2, n), 7.0, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_ln_gemm(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), 1e-6, _lib.ptr(wd), _lib.ptr(biasd), _lib.ptr(out),
-                                 rows, n, 384, code, _lib.DTYPES[dt], _lib.stream_ptr()))
-    got = out.float().cpu().double()
-    assert (got[rows:] == 7.0).all(), 'wrote past the last row'
-    h = F.layer_norm(x.double(), (384,), lg.double(), lb.double(), 1e-6).to(TDT[dt]).double()
-    ref = h @ w.double().t() + bias.double()
-    if epi == 'gelu':
-        ref = F.gelu(ref)
-    # a LayerNorm output on a rounding boundary may round the other way than in fp64: allow one operand ulp of slack
-    assert ((got[:rows] - ref).abs() <= EPS[dt] * ref.abs() * 1.01 + 3 * EPS[dt] + 1e-3).all()
-    assert rel_fro(got[:rows], ref) <= EPS[dt]
-    # the unfused pair of kernels
-    hd = torch.empty(rows, 384, dtype=TDT[dt], device=gpu)
-    out2 = torch.empty(rows, n, dtype=TDT[dt], device=gpu)
-    _lib.check(lib.vittf_layernorm(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), _lib.ptr(hd), rows, 384, 1e-6, _lib.DTYPES[dt],
-                                   _lib.stream_ptr()))
-    _lib.check(lib.vittf_gemm(_lib.ptr(hd), _lib.ptr(wd), _lib.ptr(biasd), _lib.ptr(out2), rows, n, 384, code, 0,
-                              _lib.DTYPES[dt], _lib.stream_ptr()))
-    assert rel_fro(got[:rows], out2.float().cpu().double()) <= EPS[dt] / 2
-
-
-@pytest.fixture(params=['1', '2'])
-def rows_wm(request, monkeypatch):
-    """both workgroup shapes of the whole-row GEMM: 128 rows x 2 per CU (default) and 256 rows x 1 per CU"""
-    monkeypatch.setenv('VITTF_ROWS_WM', request.param)
-    return request.param
-
-
-@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('rows,k', [(256, 384), (1030, 1536), (33000, 384), (4097 * 3, 1536), (100, 384)])
-def test_gemm_residual_ln(gpu, dt, rows, k, rows_wm):
+def test_gemm_residual_ln(gpu, dt, rows, k):
     """x += a . w^T + bias and h = LayerNorm(x) in one call (whole-row GEMM with the LayerNorm in its epilogue + the tiled /
     LayerNorm kernels for the rows beyond the last full 256-row tile) against fp64 and against the separate kernels."""
     _residual_ln_case(gpu, dt, rows, 384, k)

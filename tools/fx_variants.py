@@ -1,5 +1,5 @@
-"""Times the builds made by tools/fx_variants.sh (csrc/tail_fx.hip, the role-split block tail) against each other and against
-the library's vittf_block_tail (csrc/mlp.hip), interleaved in one process: HIP events around repeated launches, BATCH slices
+"""Times the builds made by tools/fx_variants.sh (csrc/tail_fx.hip, the block tail) against each other and against the library's
+own build, interleaved in one process: HIP events around repeated launches, BATCH slices
 of 4097 tokens.  Builds with bit 1 set run the main phase only (no tile boundary) and builds with bits 2 / 4 / 8 drop one
 ingredient each: their results are wrong by construction.  Builds with bit 16 also print in-kernel stamps."""
 import ctypes
@@ -17,7 +17,6 @@ from vit_tf_amd import _lib  # noqa: E402
 
 ARGS = ([ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
-ARGS_Q = ARGS[:15] + [ctypes.c_void_p, ctypes.c_void_p] + ARGS[15:]
 
 
 def main():
@@ -28,8 +27,7 @@ def main():
     w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).half().to(dev)
     w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).half().to(dev)
     wp = (torch.randn(d, d, generator=g) / d ** 0.5).half().to(dev)
-    wfx = vt.weights.pack_tail_fx_weights(wp[None], w1[None], w2[None])[0].contiguous()
-    wold = vt.weights.pack_block_tail_weights(wp[None], w1[None], w2[None])[0].contiguous()
+    wfx = vt.weights.pack_block_tail_weights(wp[None], w1[None], w2[None])[0].contiguous()
     b1 = torch.randn(4 * d, generator=g).to(dev); b2 = torch.randn(d, generator=g).to(dev)
     hh = torch.randn(rows, d, generator=g).half().to(dev)
     lg = torch.ones(d, device=dev); lb = torch.zeros(d, device=dev)
@@ -38,41 +36,18 @@ def main():
     ctr = torch.zeros(1, dtype=torch.int32, device=dev)
     fns = []
     lib = _lib.load()
-    wq = (1.3 * torch.randn(3 * d, d, generator=g) / d ** 0.5).half().to(dev)
-    bq = torch.randn(3 * d, generator=g).to(dev)
-    qkv = torch.empty(rows, 3 * d, dtype=torch.float16, device=dev)
-    wfq = vt.weights.pack_tail_fx_qkv_weights(wp[None], w1[None], w2[None], wq[None])[0].contiguous()
-
-    def old_plus_gemm(*a):          # what the engine runs today: the one-wave block tail, then the qkv GEMM on its LayerNorm output
-        rc = lib.vittf_block_tail(*a)
-        return rc or lib.vittf_gemm(hn.data_ptr(), wq.data_ptr(), bq.data_ptr(), qkv.data_ptr(), rows, 3 * d, d, _lib.EPI_BIAS_QKV, 0,
-                                    _lib.DTYPES['fp16'], _lib.stream_ptr())
-
-    def q_entry(f):
-        f.restype = ctypes.c_int
-        f.argtypes = ARGS_Q
-        return lambda *a: f(*a[:15], bq.data_ptr(), qkv.data_ptr(), *a[15:])
-    fns.append(('lib:mlp.hip', lib.vittf_block_tail, wold, None))
-    fns.append(('lib:mlp+qkvgemm', old_plus_gemm, wold, None))
-    if hasattr(lib, 'vittf_block_tail_qkv') and os.environ.get('FX_LIB', '1') == '1':
-        fns.append(('lib:tail_qkv', q_entry(lib.vittf_block_tail_qkv), wfq, None))
-    if hasattr(lib, 'vittf_block_tail_fx') and os.environ.get('FX_LIB', '1') == '1':
-        lib.vittf_block_tail_fx.restype = ctypes.c_int
-        lib.vittf_block_tail_fx.argtypes = ARGS
-        fns.append(('lib:tail_fx', lib.vittf_block_tail_fx, wfx, None))
+    fns.append(('lib:tail_fx', lib.vittf_block_tail, wfx, None))
     paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'micro', 'build', 'libfx_v*.so')),
                    key=lambda p: (int(re.search(r'_v(\d+)', p).group(1)), p))
     for p in paths:
         so = ctypes.CDLL(p)
-        f = so.vittf_block_tail_fx
+        f = so.vittf_block_tail
         f.restype = ctypes.c_int
         f.argtypes = ARGS
         v = re.search(r'_v(\w+)\.so', p).group(1)
         # main-phase-only builds stream 100 steps per tile: the main steps of the packed stream
         w = wfx[12:].contiguous() if int(re.match(r'\d+', v).group(0)) & 1 else wfx
         fns.append((v, f, w, so))
-        if not int(re.match(r'\d+', v).group(0)) & 1 and hasattr(so, 'vittf_block_tail_qkv'):
-            fns.append((v + 'q', q_entry(so.vittf_block_tail_qkv), wfq, so))
 
     def run(f, w):
         rc = f(hh.data_ptr(), w.data_ptr(), b2.data_ptr(), lg.data_ptr(), lb.data_ptr(), b1.data_ptr(), b2.data_ptr(), x.data_ptr(),

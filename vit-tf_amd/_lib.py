@@ -17,12 +17,15 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_KFEAT, EPI_BIAS_QKV = 0, 1, 2, 3
 
 class VitConfig(C.Structure):
     _fields_ = [('embed_dim', C.c_int32), ('depth', C.c_int32), ('heads', C.c_int32), ('patch', C.c_int32),
-                ('dtype', C.c_int32), ('ln_eps', C.c_float), ('attention_fp8', C.c_int32)]
+                ('dtype', C.c_int32), ('ln_eps', C.c_float), ('attention_fp8', C.c_int32), ('flags', C.c_int32)]
+
+
+CFG_SEPARATE_LN, CFG_UNSCALED_Q, CFG_FP8_HEAD_SCALES = 1, 2, 4
 
 
 class VitWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        'pe_w_t', 'pe_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'mlp_packed', 'tail_packed',
+        'pe_w_t', 'pe_b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'tail_packed', 'qkv_packed',
         'ln1_g', 'ln1_b', 'ln2_g', 'ln2_b')]
 
 
@@ -66,12 +69,10 @@ SIGNATURES = {
     'vittf_layernorm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, C.c_float, _i32, _vp]),
     'vittf_gemm': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vittf_gemm_residual_ln': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp]),
-    'vittf_ln_gemm': (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
-    'vittf_mlp_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     'vittf_block_tail_workspace_bytes': (_sz, []),
     'vittf_block_tail': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
-    'vittf_block_tail_fx': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
-    'vittf_block_tail_qkv': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    'vittf_gemm_as_workspace_bytes': (_sz, []),
+    'vittf_gemm_as': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'vittf_attention': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vittf_attention_rescale_count': (_i64, [_i32]),
     'vittf_attention_fp8_workspace_bytes': (_sz, [_i32, _i32, _i32]),
@@ -128,7 +129,7 @@ def load():
 
 KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention', 'mlp', 'gemm_qkv', 'gemm_proj', 'gemm_fc1', 'gemm_fc2',
                   'similarity')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def profiler_enable(on=True, classes=None):

@@ -343,27 +343,20 @@ extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_
   const int total = (int)total64;
   const float c = 0.125f * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)stream;
-  if (q_prescaled && (dtype == VITTF_BF16 || dtype == VITTF_FP16)) {
-    // default for pre-scaled q (round 3): attention_pp64.hip, two 32-row query blocks per wave taking turns, two waves per SIMD
-    // (6.04 ms per 256-slice launch where round 2's 32-rows-per-wave pipelined kernel took 6.66).  VITTF_ATTN_PIPE=0: the
-    // round-1 lazy-maximum kernel below (read per call: the tests switch it).
-    const char* e = getenv("VITTF_ATTN_PIPE");
-    if (!e || atoi(e) != 0) {
-      vittf_note_kernel(VITTF_KERNEL_ATTENTION, "attn_pp64_kernel");
-      return vittf_attention_pp64(qkv, out, batch, tokens, heads, dtype, st);
-    }
+  if (q_prescaled) {
+    // pre-scaled q (what the engine runs): attention_pp64.hip, two 32-row query blocks per wave taking turns, two waves per SIMD
+    if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
+    vittf_note_kernel(VITTF_KERNEL_ATTENTION, "attn_pp64_kernel");
+    return vittf_attention_pp64(qkv, out, batch, tokens, heads, dtype, st);
   }
-#define VITTF_ATTN_LAUNCH(DTV, PREV)                                                                        \
-  hipLaunchKernelGGL((attn_kernel<DTV, PREV>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,   \
+  // q as the model produces it: the online-maximum kernel of this file
+#define VITTF_ATTN_LAUNCH(DTV)                                                                              \
+  hipLaunchKernelGGL((attn_kernel<DTV, false>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,  \
                      (unsigned short*)out, tokens, heads, q_tiles, total, c)
-  vittf_note_kernel(VITTF_KERNEL_ATTENTION, q_prescaled ? "attn_kernel<lazy maximum>" : "attn_kernel<online maximum>");
-  if (dtype == VITTF_BF16) {
-    if (q_prescaled) VITTF_ATTN_LAUNCH(VITTF_BF16, true); else VITTF_ATTN_LAUNCH(VITTF_BF16, false);
-  } else if (dtype == VITTF_FP16) {
-    if (q_prescaled) VITTF_ATTN_LAUNCH(VITTF_FP16, true); else VITTF_ATTN_LAUNCH(VITTF_FP16, false);
-  } else {
-    return VITTF_ERR_INVALID_ARG;
-  }
+  vittf_note_kernel(VITTF_KERNEL_ATTENTION, "attn_kernel<online maximum>");
+  if (dtype == VITTF_BF16) VITTF_ATTN_LAUNCH(VITTF_BF16);
+  else if (dtype == VITTF_FP16) VITTF_ATTN_LAUNCH(VITTF_FP16);
+  else return VITTF_ERR_INVALID_ARG;
 #undef VITTF_ATTN_LAUNCH
   return vittf_check_launch();
 }

@@ -10,7 +10,7 @@
 //   H    h16  [rows][D]      LayerNorm output / attention output (MFMA operand)
 //   QKV  h16  [rows][3D]     attention input; QKV|O is re-used as the [rows][4D] MLP hidden buffer
 //   O    h16  [rows][D]
-//   (fp8 attention operands, opt-in)   tile counter of the block-tail kernel (4 bytes; one workspace = one stream)
+//   (fp8 attention operands, opt-in)   tile counter of the block-tail / qkv kernels (4 bytes; one workspace = one stream)
 // Everything is enqueued on the caller's stream; nothing synchronises with the host.
 #include "vittf_common.h"
 
@@ -129,18 +129,22 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   { ProfScope ps(VITTF_KERNEL_PATCH_EMBED, stream); rc = vittf_patch_embed(cfg, w, pos, view, slice0, batch, X, stream); }
   if (rc) return rc;
   const size_t esz = 2;
-  // ViT-S, opt-in (VITTF_LN_FUSED=1): LayerNorm computed inside the qkv / fc1 GEMMs' activation loader (vittf_ln_gemm).
-  // Parity-green, but the fp32 rows are then fetched once per 384-column panel (3-4 x 201 MB instead of 3-4 x 100 MB of
-  // 16-bit rows), which costs more than the LayerNorm launches: 1690 against 1720 slices/s on the 256^3 workload.
-  static const bool ln_fused_env = [] { const char* e = getenv("VITTF_LN_FUSED"); return e && atoi(e) != 0; }();
-  const bool ln_fused = ln_fused_env && d == 384 && !(w->mlp_packed) && !(w->tail_packed);
-  // Default (D = 384 / 768): every LayerNorm but the first rides on the epilogue of the residual GEMM in front of it
-  // (vittf_gemm_residual_ln: proj -> norm2, fc2 -> the next block's norm1); VITTF_RESIDUAL_LN=0 keeps them separate.
-  static const bool res_ln_env = [] { const char* e = getenv("VITTF_RESIDUAL_LN"); return !e || atoi(e) != 0; }();
-  const bool res_ln = res_ln_env && (d == 384 || d == 768) && !ln_fused;
+  // Every LayerNorm but the first rides on the kernel in front of it (D = 384: the block tail; D = 768: the epilogue of the
+  // residual GEMM, vittf_gemm_residual_ln: proj -> norm2, fc2 -> the next block's norm1).  VITTF_CFG_SEPARATE_LN: own launches.
+  const bool res_ln = !(cfg->flags & VITTF_CFG_SEPARATE_LN) && (d == 384 || d == 768);
+  // q pre-scaled by log2(e) / 8 in the qkv epilogue + the two-blocks-per-wave attention kernel; VITTF_CFG_UNSCALED_Q: q as the
+  // model produces it and the online-maximum kernel.
+  const int pre = (cfg->flags & VITTF_CFG_UNSCALED_Q) ? 0 : 1;
+  // fp8 attention at D = 768 (BASELINE configs[3]): q and k leave the qkv GEMM as fp8 rows with their own block scales, v
+  // with its absolute maxima collected on the way (vittf_gemm_qkv_fp8 + vittf_attention_fp8_rows) -- no absmax pass, a
+  // quantise pass over the v third only.  VITTF_CFG_FP8_HEAD_SCALES: the per-(slice, head) scales of round 2 (three launches).
+  const bool fp8_rows = !(cfg->flags & VITTF_CFG_FP8_HEAD_SCALES) && cfg->attention_fp8 && pre && d >= 768 && d % 256 == 0;
+  // D = 384 with packed weights: the block tail (tail_fx.hip) and the activation-stationary qkv GEMM (gemm_as.hip)
+  const bool tail = d == 384 && w->tail_packed && res_ln;
+  const bool qkv_as = d == 384 && w->qkv_packed && !cfg->attention_fp8;
   for (int l = 0; l < L; ++l) {
     const char* qkv_w = (const char*)w->qkv_w + (size_t)l * 3 * d * d * esz;
-    if (res_ln ? l == 0 : (!ln_fused || l == L - 1)) {
+    if (res_ln ? l == 0 : true) {
       ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
       rc = vittf_layernorm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
       if (rc) return rc;
@@ -152,22 +156,13 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
                         k_out, rows, d, d,
                         VITTF_EPI_KFEAT, tokens, dt, stream);
     }
-    // Default: q pre-scaled by log2(e)/8 in the qkv epilogue + the lazy-maximum attention kernel (168 VGPRs, 3 waves per
-    // SIMD): 0.78 ms per launch in the pipeline against 0.87 ms for the online-maximum kernel (VITTF_ATTN_PRESCALED=0).
-    static const int pre = [] { const char* e = getenv("VITTF_ATTN_PRESCALED"); return e ? atoi(e) : 1; }();
-    // fp8 attention at D = 768 (BASELINE configs[3]): q and k leave the qkv GEMM as fp8 rows with their own block scales, v
-    // with its absolute maxima collected on the way (vittf_gemm_qkv_fp8 + vittf_attention_fp8_rows) -- no absmax pass, a
-    // quantise pass over the v third only.  VITTF_FP8_ROWS=0: the per-(slice, head) scales of round 2 (three launches).
-    static const bool fp8_rows_env = [] { const char* e = getenv("VITTF_FP8_ROWS"); return !e || atoi(e) != 0; }();
-    const bool fp8_rows = fp8_rows_env && cfg->attention_fp8 && pre && !ln_fused && d >= 768 && d % 256 == 0;
     { ProfScope ps(VITTF_KERNEL_GEMM_QKV, stream);
       if (fp8_rows)
         rc = vittf_gemm_qkv_fp8(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, tokens, cfg->heads, dt,
                                 base + lay.fp8, lay.fp8_bytes, stream);
-      else if (ln_fused)
-        rc = vittf_ln_gemm(X, w->ln1_g + (size_t)l * d, w->ln1_b + (size_t)l * d, cfg->ln_eps, qkv_w,
-                           w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d, pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, dt,
-                           stream);
+      else if (qkv_as)
+        rc = vittf_gemm_as(H, (const char*)w->qkv_packed + (size_t)l * 3 * d * d * esz, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d,
+                           pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, dt, base + lay.tile_ctr, stream);
       else
         rc = vittf_gemm(H, qkv_w, w->qkv_b + (size_t)l * 3 * d, QKV, rows, 3 * d, d,
                         pre ? VITTF_EPI_BIAS_QKV : VITTF_EPI_BIAS, 0, dt, stream); }
@@ -180,11 +175,11 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
       else
         rc = vittf_attention(QKV, O, batch, tokens, cfg->heads, dt, pre, stream); }
     if (rc) return rc;
-    if (d == 384 && w->tail_packed && res_ln) {
+    if (tail) {
       // everything behind the attention -- proj, residual, norm2, fc1, GELU, fc2, residual, the next block's norm1 -- in one
       // launch: the residual rows are read once and written once, nothing else of it reaches HBM
       ProfScope ps(VITTF_KERNEL_MLP, stream);
-      rc = vittf_block_tail(O, (const char*)w->tail_packed + (size_t)l * 108 * 12288 * esz, w->proj_b + (size_t)l * d,
+      rc = vittf_block_tail(O, (const char*)w->tail_packed + (size_t)l * VITTF_TAIL_STEPS * 12288 * esz, w->proj_b + (size_t)l * d,
                             w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, w->fc1_b + (size_t)l * 4 * d,
                             w->fc2_b + (size_t)l * d, X, rows, d, dt, w->ln1_g + (size_t)(l + 1) * d,
                             w->ln1_b + (size_t)(l + 1) * d, cfg->ln_eps, H, base + lay.tile_ctr, stream);
@@ -199,39 +194,24 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
         rc = vittf_gemm(O, (const char*)w->proj_w + (size_t)l * d * d * esz, w->proj_b + (size_t)l * d, X, rows, d, d,
                         VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
     if (rc) return rc;
-    if (!ln_fused && !res_ln) {
+    if (!res_ln) {
       ProfScope ps(VITTF_KERNEL_LAYERNORM, stream);
       rc = vittf_layernorm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, H, rows, d, cfg->ln_eps, dt, stream);
       if (rc) return rc;
     }
-    if (d == 384 && w->mlp_packed) {
-      // fc1 -> GELU -> fc2 -> residual (-> the next block's norm1) in one launch: the hidden activation stays on the chip
-      ProfScope ps(VITTF_KERNEL_MLP, stream);
-      rc = vittf_mlp_fused(H, (const char*)w->mlp_packed + (size_t)l * 4 * d * d * 2 * esz, w->fc1_b + (size_t)l * 4 * d,
-                           w->fc2_b + (size_t)l * d, X, rows, d, dt, res_ln ? w->ln1_g + (size_t)(l + 1) * d : nullptr,
-                           res_ln ? w->ln1_b + (size_t)(l + 1) * d : nullptr, cfg->ln_eps, res_ln ? H : nullptr,
-                           base + lay.tile_ctr, stream);
-      if (rc) return rc;
-    } else {
-      { ProfScope ps(VITTF_KERNEL_GEMM_FC1, stream);
-        if (ln_fused)
-          rc = vittf_ln_gemm(X, w->ln2_g + (size_t)l * d, w->ln2_b + (size_t)l * d, cfg->ln_eps,
-                             (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows, 4 * d,
-                             d, VITTF_EPI_BIAS_GELU, dt, stream);
-        else
-          rc = vittf_gemm(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows,
-                          4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream); }
-      if (rc) return rc;
-      { ProfScope ps(VITTF_KERNEL_GEMM_FC2, stream);
-        if (res_ln)   // (l + 1 < L always holds here: the last block returns above)
-          rc = vittf_gemm_residual_ln(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows,
-                                      d, 4 * d, dt, w->ln1_g + (size_t)(l + 1) * d, w->ln1_b + (size_t)(l + 1) * d,
-                                      cfg->ln_eps, H, stream);
-        else
-          rc = vittf_gemm(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
-                          4 * d, VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
-      if (rc) return rc;
-    }
+    { ProfScope ps(VITTF_KERNEL_GEMM_FC1, stream);
+      rc = vittf_gemm(H, (const char*)w->fc1_w + (size_t)l * 4 * d * d * esz, w->fc1_b + (size_t)l * 4 * d, G, rows,
+                      4 * d, d, VITTF_EPI_BIAS_GELU, 0, dt, stream); }
+    if (rc) return rc;
+    { ProfScope ps(VITTF_KERNEL_GEMM_FC2, stream);
+      if (res_ln)   // (l + 1 < L always holds here: the last block returns above)
+        rc = vittf_gemm_residual_ln(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows,
+                                    d, 4 * d, dt, w->ln1_g + (size_t)(l + 1) * d, w->ln1_b + (size_t)(l + 1) * d,
+                                    cfg->ln_eps, H, stream);
+      else
+        rc = vittf_gemm(G, (const char*)w->fc2_w + (size_t)l * 4 * d * d * esz, w->fc2_b + (size_t)l * d, X, rows, d,
+                        4 * d, VITTF_EPI_BIAS_RESIDUAL, 0, dt, stream); }
+    if (rc) return rc;
   }
   return VITTF_OK;
 }

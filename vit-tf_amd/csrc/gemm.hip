@@ -225,7 +225,7 @@ int launch_gemm(const void* a, const void* w, const float* bias, void* out, int6
   const int total = m_tiles * n_tiles;
   // 1 = one 32 KB operand stage and four workgroups per CU (default: +16 % on the K = 384 shapes, whose six
   // K steps are too short for a two-stage pipeline to cover the load latency); 2 = double buffer, two per CU
-  static const int nstage = [] { const char* e = getenv("VITTF_GEMM_STAGES"); return e ? atoi(e) : 1; }();
+  constexpr int nstage = 1;      // (one 32 KB stage x four workgroups per CU; the double-buffered form measured slower on every shape)
   const size_t lds = nstage == 1 ? (size_t)BM * (BN * 2 + 16) : (size_t)4 * TILE_BYTES;   // stage(s) / padded C tile (16-bit: 128 x 272 B; fp32 half tile: 128 x 272 B)
   const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Wp = (const unsigned short*)w;
@@ -259,22 +259,16 @@ int launch_gemm(const void* a, const void* w, const float* bias, void* out, int6
 
 }  // namespace
 
-int vittf_gemm_ws(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
-                  int32_t epilogue, int32_t dtype, hipStream_t st);   // gemm_ws.hip; 1 = not covered
-
 int vittf_gemm_rows(const void* a, const void* w, const float* bias, float* x, int64_t rows, int32_t n, int32_t k,
                     int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h, hipStream_t st);   // gemm_rows.hip
 
 int vittf_gemm_pp(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n, int32_t k,
                   int32_t epilogue, int32_t tokens, int32_t dtype, hipStream_t st);   // gemm_pp.hip; 1 = not covered
 
-// VITTF_GEMM_PP (default 1): K >= 768 with N % 256 == 0 (the ViT-B linears) on the persistent 256 x 256 kernel of
-// gemm_pp.hip; 0: gemm.hip's 128 x 128 tiles.  VITTF_PP_RESIDUAL: the residual linears with 768 output columns whose K is at
-// least this (default 3072: fc2 -- the LayerNorm behind it then runs as its own launch instead of in the whole-row kernel's
-// epilogue: 1.56 against 1.87 ms per 64 slices; proj, K = 768, stays on the whole-row kernel; 768: both; 0: neither).
-static bool use_pp() { static const bool v = [] { const char* e = getenv("VITTF_GEMM_PP"); return !e || atoi(e) != 0; }(); return v; }
-static int pp_residual_min_k() { static const int v = [] { const char* e = getenv("VITTF_PP_RESIDUAL"); return e ? atoi(e) : 3072; }(); return v; }
-static bool use_pp_residual(int k) { const int m = pp_residual_min_k(); return m > 0 && k >= m; }
+// K >= 768 with N % 256 == 0 (the ViT-B linears) run on the persistent 256 x 256 kernel of gemm_pp.hip.  Residual linears with
+// 768 output columns take it from K = 3072 on (fc2: the LayerNorm behind it then runs as its own launch instead of in the
+// whole-row kernel's epilogue: 1.56 against 1.87 ms per 64 slices); proj, K = 768, stays on the whole-row kernel.
+static bool use_pp_residual(int k) { return k >= 3072; }
 
 extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void* out, int64_t rows, int32_t n,
                           int32_t k, int32_t epilogue, int32_t tokens, int32_t dtype, void* stream) {
@@ -283,21 +277,13 @@ extern "C" int vittf_gemm(const void* a, const void* w, const float* bias, void*
   if (epilogue == VITTF_EPI_KFEAT && tokens < 2) return VITTF_ERR_INVALID_ARG;
   if (rows / BM + 1 > (1 << 20)) return VITTF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
-  // K = 384 (ViT-S): weight-stationary kernel (VITTF_GEMM_WS=0 keeps everything on the tiled kernel below)
-  static const int use_ws = [] { const char* e = getenv("VITTF_GEMM_WS"); return e ? atoi(e) : 1; }();
-  if (use_ws) {
-    const int rc = vittf_gemm_ws(a, w, bias, out, rows, n, k, epilogue, dtype, st);
-    if (rc != 1) return rc;
-  }
-  // residual epilogue with 384 / 768 output columns (ViT-S / ViT-B proj and fc2): whole-row kernel (VITTF_GEMM_ROWS=0:
-  // tiled kernel only)
-  static const bool use_rows = [] { const char* e = getenv("VITTF_GEMM_ROWS"); return !e || atoi(e) != 0; }();
-  const bool pp_first = use_pp() && use_pp_residual(k) && n == 768 && k >= 768;
-  if (use_rows && !pp_first && epilogue == VITTF_EPI_BIAS_RESIDUAL && (n == 384 || n == 768)) {
+  // residual epilogue with 384 / 768 output columns (ViT-S / ViT-B proj and fc2): whole-row kernel
+  const bool pp_first = use_pp_residual(k) && n == 768 && k >= 768;
+  if (!pp_first && epilogue == VITTF_EPI_BIAS_RESIDUAL && (n == 384 || n == 768)) {
     const int rc = vittf_gemm_rows(a, w, bias, (float*)out, rows, n, k, dtype, nullptr, nullptr, 0.f, nullptr, st);
     if (rc != 1) return rc;
   }
-  if (use_pp()) {
+  {
     const int rc = vittf_gemm_pp(a, w, bias, out, rows, n, k, epilogue, tokens, dtype, st);
     if (rc != 1) return rc;
   }
@@ -316,8 +302,7 @@ extern "C" int vittf_gemm_residual_ln(const void* a, const void* w, const float*
   if (!a || !w || !bias || !x || !ln_g || !ln_b || !h || rows <= 0 || n <= 0 || k <= 0) return VITTF_ERR_INVALID_ARG;
   if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
-  static const bool use_rows = [] { const char* e = getenv("VITTF_GEMM_ROWS"); return !e || atoi(e) != 0; }();
-  if (use_rows && (n == 384 || n == 768) && !(use_pp() && use_pp_residual(k) && n == 768 && k >= 768)) {
+  if ((n == 384 || n == 768) && !(use_pp_residual(k) && n == 768 && k >= 768)) {
     const int rc = vittf_gemm_rows(a, w, bias, x, rows, n, k, dtype, ln_g, ln_b, ln_eps, h, st);
     if (rc != 1) return rc;
   }

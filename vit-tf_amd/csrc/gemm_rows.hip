@@ -271,9 +271,7 @@ int vittf_gemm_rows(const void* a, const void* w, const float* bias, float* x, i
   if (dtype != VITTF_BF16 && dtype != VITTF_FP16) return VITTF_ERR_INVALID_ARG;
   // Workgroup shape by K (never by the row count: results must not depend on how the rows are batched): the 256-row
   // shape for the long-K linear (fc2: 239 against 254 ms per 3072 slices), the 128-row one for proj (123 against 127).
-  // VITTF_ROWS_WM=1|2 forces one shape (read per call: the tests switch it).
-  const char* wm_env = getenv("VITTF_ROWS_WM");
-  const int wm = n == 768 ? 1 : (wm_env ? (atoi(wm_env) == 2 ? 2 : 1) : (k >= 1024 ? 2 : 1));
+  const int wm = n == 768 ? 1 : (k >= 1024 ? 2 : 1);
   const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Wp = (const unsigned short*)w;
   const bool ln = ln_g && ln_b && h;

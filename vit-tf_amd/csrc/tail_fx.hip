@@ -42,10 +42,6 @@ constexpr int MSTEPS = 2 * UNITS + LAG;      // main steps of a row tile
 #ifndef FX_NSLOT
 #define FX_NSLOT 4
 #endif
-#ifndef FX_STAGGER_PHASES      // start offsets between the workgroups (see the kernel): phases x sleeps x 8128 cycles
-#define FX_STAGGER_PHASES 0
-#define FX_STAGGER_SLEEPS 0
-#endif
 // timing-only builds (tools/fx_variants.sh; never in libvittf.so): 1 = main phase only (no tile boundary), 2 = no GELU
 // arithmetic, 4 = no LDS-DMA inside the steps, 8 = no fragment refills, 16 = stamps, 32 = steps without their barrier,
 // 64 = no raised priority for the F waves
@@ -69,16 +65,6 @@ constexpr int LDS_BYTES = NEXT_OFF + 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 static_assert(AHEAD >= 3, "ring depth");
 static_assert(32 * STG_ROW <= PBH && 4 * AF_SLOT <= PBH, "pair buffer");
-// ---- the form with the NEXT block's qkv projection folded in (QKV = true; run_fq / run_xq below)
-constexpr int BSTEPS = 72;                   // boundary steps of a row tile: the F wave runs one k half of a qkv unit in each
-constexpr int QUNITS = 3 * D / 32;           // 36 output tiles of 32 qkv columns
-constexpr int NSEQ_Q = BSTEPS + MSTEPS;
-constexpr int PBQ = 3 * PBH;                 // pair region: half 0 | half 1 | the F wave's output staging
-constexpr int CQ_OFF = PB_OFF + 4 * PBQ;     // constants, in floats: b2 | gamma, beta of the next norm1 | proj bias | gamma, beta of norm2
-constexpr int CQ_B2 = 0, CQ_G1 = D, CQ_E1 = 2 * D, CQ_BP = 3 * D, CQ_G2 = 4 * D, CQ_E2 = 5 * D, CQ_N = 6 * D;
-constexpr int NEXTQ_OFF = CQ_OFF + CQ_N * 4;
-constexpr int LDSQ_BYTES = NEXTQ_OFF + 16;
-static_assert(LDSQ_BYTES <= 160 * 1024, "LDS (qkv form)");
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
@@ -92,10 +78,9 @@ typedef __attribute__((address_space(3))) volatile unsigned* lds_u32_ptr;
 struct Ring {                  // where the weight stream stands (wave-uniform)
   i32x4_t rsrc;                // descriptor over one layer's NSEQ packed steps
   unsigned dma_dst;            // LDS byte address of slot 0
-  int src0, src_hi;            // byte offsets inside a step of this wave's pieces 0 .. 2 / 3 .. 5
-  int g;                       // stream position of the step being computed (0 .. nseq - 1, wraps with the row tiles)
+  int src0;                    // byte offset inside a step of this wave's first piece
+  int g;                       // stream position of the step being computed (0 .. NSEQ - 1, wraps with the row tiles)
   int slot;                    // its ring slot
-  int nseq;                    // steps per row tile
 };
 
 __device__ __forceinline__ s16x8_t ld_frag(const unsigned (&base)[4], int f) {
@@ -174,16 +159,16 @@ __device__ __forceinline__ void sync_wait() {
   else asm volatile("s_barrier" ::: "memory");
 }
 
-__device__ __forceinline__ int ring_next(const Ring& st) { return st.g + AHEAD < st.nseq ? st.g + AHEAD : st.g + AHEAD - st.nseq; }
+__device__ __forceinline__ int ring_next(const Ring& st) { return st.g + AHEAD < NSEQ ? st.g + AHEAD : st.g + AHEAD - NSEQ; }
 __device__ __forceinline__ int ring_free(const Ring& st) { return st.slot == 0 ? NSLOT - 1 : st.slot - 1; }
 __device__ __forceinline__ void ring_advance(Ring& st) {
-  st.g = st.g + 1 == st.nseq ? 0 : st.g + 1;
+  st.g = st.g + 1 == NSEQ ? 0 : st.g + 1;
   st.slot = st.slot + 1 == NSLOT ? 0 : st.slot + 1;
 }
 // piece i (0 .. 5) of this X wave for the step AHEAD, into the slot the barrier of this step has freed
 __device__ __forceinline__ void ring_piece(const Ring& st, int i, int g_next, int slot_free) {
   if (V_NO_DMA) return;
-  const int off = i < 3 ? st.src0 + i * 1024 : st.src_hi + (i - 3) * 1024;
+  const int off = st.src0 + i * 1024;
   lds_dma16_keep(st.rsrc, st.dma_dst + slot_free * SB + off, (int)((threadIdx.x & 63) * 16), g_next * SB + off);
 }
 __device__ __forceinline__ void rotate_bases(const Ring& st, unsigned (&base)[4]) {
@@ -295,14 +280,13 @@ __device__ __forceinline__ constexpr int af_off(int s) { return (((s >> 2) & 1) 
 struct Ctx {
   const unsigned short* abuf; const unsigned short* wpk; float* x; unsigned short* hout; unsigned* tile_ctr;
   int64_t rows; float ln_eps; int ntiles; int tile; unsigned lds0;
-  unsigned short* qkv_out; const float* qkv_b; const float* b1;      // (qkv form only)
 };
 __device__ __forceinline__ unsigned uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) {
   const uint64_t v = reinterpret_cast<uint64_t>(p);
   return reinterpret_cast<T*>(((uint64_t)uni((unsigned)(v >> 32)) << 32) | uni((unsigned)v));
 }
-#define FX_ROLE_ENV(QKV_)                                                                                                 \
+#define FX_ROLE_ENV                                                                                                       \
   const unsigned short* const abuf = uni_ptr(c.abuf);                                                                     \
   float* const x = uni_ptr(c.x);                                                                                          \
   unsigned short* const hout = uni_ptr(c.hout);                                                                           \
@@ -316,20 +300,18 @@ template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                             \
   const int rb = wave & 3;                                                                                                \
   const int h = lane >> 5, l31 = lane & 31;                                                                               \
-  unsigned cl = lds0 + ((QKV_) ? CQ_OFF : CONST_OFF) + 16 * h;                                                            \
+  unsigned cl = lds0 + CONST_OFF + 16 * h;                                                                                \
   asm volatile("" : "+v"(cl));                                                                                            \
   auto cst4 = [&](int i) { return *(lds_f4_ptr)(cl + 4 * i); };      /* floats i .. i + 3 (+ 4 h) of the constants */       \
-  const unsigned nxt = lds0 + ((QKV_) ? NEXTQ_OFF : NEXT_OFF);                                                            \
+  const unsigned nxt = lds0 + NEXT_OFF;                                                                                   \
   Ring st;                                                                                                                \
-  st.nseq = (QKV_) ? NSEQ_Q : NSEQ;                                                                                       \
-  st.rsrc = lds_dma_rsrc(uni_ptr(c.wpk), (unsigned)(st.nseq * SB));                                                       \
-  st.src0 = (QKV_) ? rb * 3072 : rb * 6144;           /* qkv form: three pieces of each half of a step per X wave */       \
-  st.src_hi = (QKV_) ? HB + rb * 3072 : rb * 6144 + 3072;                                                                 \
+  st.rsrc = lds_dma_rsrc(uni_ptr(c.wpk), (unsigned)(NSEQ * SB));                                                          \
+  st.src0 = rb * (PIECES * 1024);                                                                                         \
   st.dma_dst = lds0;                                                                                                      \
   st.g = 0;                                                                                                               \
   st.slot = 0;                                                                                                            \
   const int aoff0 = tile_off(l31, h);                                                                                     \
-  const unsigned pbuf = lds0 + PB_OFF + rb * ((QKV_) ? PBQ : PB);      /* this pair's buffer: halves at + 0 and + PBH */    \
+  const unsigned pbuf = lds0 + PB_OFF + rb * PB;      /* this pair's buffer: halves at + 0 and + PBH */                     \
   /* a tile's slice of a [rows][width bytes] array as a buffer descriptor: rows past the end read as zero / are not written */ \
   auto tile_rsrc = [&](const void* p, int64_t tile, int row_bytes) {                                                      \
     const int64_t first = tile * 128, left = rows - first;                                                                \
@@ -344,7 +326,7 @@ template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) {
 // =============================================== F: the 16-bit rows ===============================================
 template <int DT>
 __device__ __attribute__((noinline)) void run_f(Ctx c) {
-  FX_ROLE_ENV(false);
+  FX_ROLE_ENV;
   // =============================================== F: the 16-bit rows ===============================================
   if (!V_NO_PRIO) asm volatile("s_setprio 3");     // its GELU pieces go in front of the X wave's MFMA waiting for the pipe
   unsigned pbl = pbuf + lane * 16;                 // lane-linear 16-byte slots of the pair buffer
@@ -504,7 +486,7 @@ __device__ __attribute__((noinline)) void run_f(Ctx c) {
 // =============================================== X: the fp32 rows ===============================================
 template <int DT>
 __device__ __attribute__((noinline)) void run_x(Ctx c) {
-  FX_ROLE_ENV(false);
+  FX_ROLE_ENV;
   // =============================================== X: the fp32 rows ===============================================
   unsigned base[4];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -769,52 +751,37 @@ __device__ __attribute__((noinline)) void run_x(Ctx c) {
   }
 }
 
-#include "tail_fx_qkv.inc"
-
-template <int DT, bool QKV>
+template <int DT>
 __global__ __launch_bounds__(512, 1) void tail_fx_kernel(const unsigned short* __restrict__ abuf, const unsigned short* __restrict__ wpk,
                                                          const float* __restrict__ bp, const float* __restrict__ g2, const float* __restrict__ e2,
                                                          const float* __restrict__ b1, const float* __restrict__ b2,
                                                          float* __restrict__ x, int64_t rows, const float* __restrict__ ln_g,
                                                          const float* __restrict__ ln_b, float ln_eps,
                                                          unsigned short* __restrict__ hout, int ntiles,
-                                                         unsigned* __restrict__ tile_ctr, const float* __restrict__ qkv_b,
-                                                         unsigned short* __restrict__ qkv_out, int stagger_phases, int stagger_sleeps) {
-  __shared__ __attribute__((aligned(16))) char smem[QKV ? LDSQ_BYTES : LDS_BYTES];
-  // Start offsets between the workgroups: the boundary of a tile is where ALL of its memory traffic happens (rows in, rows out:
-  // 0.6 - 1 MB per workgroup), the main phase has none; workgroups that start together stay in lockstep and hit HBM together.
-  // Workgroup b waits (b mod phases) x sleeps x 8128 cycles before it takes its first tile (the tile counter balances the rest).
-  for (int i = (int)(blockIdx.x % (unsigned)(stagger_phases > 0 ? stagger_phases : 1)) * stagger_sleeps; i > 0; --i) __builtin_amdgcn_s_sleep(127);
+                                                         unsigned* __restrict__ tile_ctr) {
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if constexpr (QKV) {
-    float* const cst = reinterpret_cast<float*>(smem + CQ_OFF);
-    for (int i = tid; i < CQ_N; i += 512) {
-      const int k = i / D, j = i - k * D;
-      cst[i] = k == 0 ? b2[j] : k == 1 ? ln_g[j] : k == 2 ? ln_b[j] : k == 3 ? bp[j] : k == 4 ? g2[j] : e2[j];
-    }
-  } else {
-    float* const cst = reinterpret_cast<float*>(smem + CONST_OFF);
-    for (int i = tid; i < C_N; i += 512) {
-      float v;
-      if (i < C_B2) v = b1[i];
-      else if (i < C_G1) v = b2[i - C_B2];
-      else if (i < C_E1) v = ln_g ? ln_g[i - C_G1] : 1.f;
-      else if (i < C_BP) v = ln_b ? ln_b[i - C_E1] : 0.f;
-      else if (i < C_G2) v = bp[i - C_BP];
-      else if (i < C_E2) v = g2[i - C_G2];
-      else v = e2[i - C_E2];
-      cst[i] = v;
-    }
+  float* const cst = reinterpret_cast<float*>(smem + CONST_OFF);
+  for (int i = tid; i < C_N; i += 512) {
+    float v;
+    if (i < C_B2) v = b1[i];
+    else if (i < C_G1) v = b2[i - C_B2];
+    else if (i < C_E1) v = ln_g ? ln_g[i - C_G1] : 1.f;
+    else if (i < C_BP) v = ln_b ? ln_b[i - C_E1] : 0.f;
+    else if (i < C_G2) v = bp[i - C_BP];
+    else if (i < C_E2) v = g2[i - C_G2];
+    else v = e2[i - C_E2];
+    cst[i] = v;
   }
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
-  const unsigned nxt = lds0 + (QKV ? NEXTQ_OFF : NEXT_OFF);
+  const unsigned nxt = lds0 + NEXT_OFF;
   if (tid == 0) *(lds_u32_ptr)nxt = atomicAdd(tile_ctr, 1u);
   __syncthreads();
   const int tile = __builtin_amdgcn_readfirstlane((int)*(lds_u32_ptr)nxt);
   if (tile >= ntiles) return;                  // (nothing requested yet)
   if (wave < 4) {                              // the first AHEAD steps of the weight stream (X waves: six pieces per step each)
-    const i32x4_t rsrc = lds_dma_rsrc(wpk, (unsigned)((QKV ? NSEQ_Q : NSEQ) * SB));
+    const i32x4_t rsrc = lds_dma_rsrc(wpk, (unsigned)(NSEQ * SB));
 #pragma unroll
     for (int u = 0; u < AHEAD; ++u)
 #pragma unroll
@@ -828,17 +795,11 @@ __global__ __launch_bounds__(512, 1) void tail_fx_kernel(const unsigned short* _
     g_fx_hwid[wave] = hw;
   }
 #endif
-  const Ctx c = {abuf, wpk, x, hout, tile_ctr, rows, ln_eps, ntiles, tile, lds0, qkv_out, qkv_b, b1};
-  if constexpr (QKV) {
-    if (wave >= 4) run_fq<DT>(c);
-    else run_xq<DT>(c);
-  } else {
-    if (wave >= 4) run_f<DT>(c);
-    else run_x<DT>(c);
-  }
+  const Ctx c = {abuf, wpk, x, hout, tile_ctr, rows, ln_eps, ntiles, tile, lds0};
+  if (wave >= 4) run_f<DT>(c);
+  else run_x<DT>(c);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the steps requested beyond the last one: land before the LDS goes away
 }
-
 
 }  // namespace
 
@@ -853,15 +814,21 @@ extern "C" int vittf_fx_stamps(unsigned long long* out, unsigned* hwid) {
 void vittf_note_kernel(int, const char*) {}
 #endif
 
-static int tail_fx_launch(bool qkv, const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g,
-                          const float* ln2_b, const float* b1, const float* b2, float* x, int64_t rows, int32_t dtype,
-                          const float* ln_g, const float* ln_b, float ln_eps, void* h_out, const float* qkv_b, void* qkv_out,
-                          void* tile_counter, void* stream) {
+extern "C" size_t vittf_block_tail_workspace_bytes(void) { return sizeof(unsigned); }
+
+extern "C" int vittf_block_tail(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g,
+                                const float* ln2_b, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
+                                int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* tile_counter,
+                                void* stream) {
+  if (!attn_out || !w_packed || !proj_b || !ln2_g || !ln2_b || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
+  if (d != D) return VITTF_ERR_INVALID_ARG;          // the register budget is sized for ViT-S
+  if ((ln_g || ln_b || h_out) && !(ln_g && ln_b && h_out)) return VITTF_ERR_INVALID_ARG;
   const int64_t tiles = (rows + 127) / 128;
   if (tiles > 0x7fffffff) return VITTF_ERR_INVALID_ARG;
-  if ((((uintptr_t)attn_out | (uintptr_t)w_packed | (uintptr_t)x | (uintptr_t)h_out | (uintptr_t)qkv_out | (uintptr_t)qkv_b | (uintptr_t)b1) & 15) != 0)
-    return VITTF_ERR_INVALID_ARG;
+  // 16-byte accesses everywhere (LDS-DMA pieces, buffer loads / stores of whole 128-byte runs)
+  if ((((uintptr_t)attn_out | (uintptr_t)w_packed | (uintptr_t)x | (uintptr_t)h_out) & 15) != 0) return VITTF_ERR_INVALID_ARG;
   if (!tile_counter || ((uintptr_t)tile_counter & 3) != 0) return VITTF_ERR_INVALID_ARG;
+  // one persistent workgroup per CU of the device this call runs on (asked per call: no state is kept between calls)
   const int cus = vittf_current_cus();
   if (cus <= 0) return VITTF_ERR_NO_DEVICE;
   unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
@@ -869,47 +836,17 @@ static int tail_fx_launch(bool qkv, const void* attn_out, const void* w_packed, 
   if (const char* e = getenv("VITTF_FX_GRID")) grid = (unsigned)atoi(e) < grid ? (unsigned)atoi(e) : grid;
 #endif
   hipStream_t st = (hipStream_t)stream;
+  // the tile counter is the caller's memory (launches on one stream are serialised; two streams bring two counters)
   unsigned* ctr = (unsigned*)tile_counter;
   if (hipMemsetAsync(ctr, 0, sizeof(unsigned), st) != hipSuccess) return VITTF_ERR_LAUNCH;
-  int phases = FX_STAGGER_PHASES, sleeps = FX_STAGGER_SLEEPS;
-#ifdef FX_STANDALONE
-  if (const char* e = getenv("VITTF_FX_PHASES")) phases = atoi(e);
-  if (const char* e = getenv("VITTF_FX_SLEEPS")) sleeps = atoi(e);
-#endif
-  if (tiles < 4 * (int64_t)grid) phases = 0;      // (short launches: nothing to spread)
-#define FX_LAUNCH(DTV, QV)                                                                                           \
-  hipLaunchKernelGGL((tail_fx_kernel<DTV, QV>), dim3(grid), dim3(512), 0, st, (const unsigned short*)attn_out,       \
+#define FX_LAUNCH(DTV)                                                                                               \
+  hipLaunchKernelGGL((tail_fx_kernel<DTV>), dim3(grid), dim3(512), 0, st, (const unsigned short*)attn_out,           \
                      (const unsigned short*)w_packed, proj_b, ln2_g, ln2_b, b1, b2, x, rows, ln_g, ln_b, ln_eps,     \
-                     (unsigned short*)h_out, (int)tiles, ctr, qkv_b, (unsigned short*)qkv_out, phases, sleeps)
-  if (dtype == VITTF_BF16) { if (qkv) FX_LAUNCH(VITTF_BF16, true); else FX_LAUNCH(VITTF_BF16, false); }
-  else if (dtype == VITTF_FP16) { if (qkv) FX_LAUNCH(VITTF_FP16, true); else FX_LAUNCH(VITTF_FP16, false); }
+                     (unsigned short*)h_out, (int)tiles, ctr)
+  if (dtype == VITTF_BF16) FX_LAUNCH(VITTF_BF16);
+  else if (dtype == VITTF_FP16) FX_LAUNCH(VITTF_FP16);
   else return VITTF_ERR_INVALID_ARG;
 #undef FX_LAUNCH
-  vittf_note_kernel(VITTF_KERNEL_MLP, qkv ? "tail_fx_kernel<qkv>" : "tail_fx_kernel");
+  vittf_note_kernel(VITTF_KERNEL_MLP, "tail_fx_kernel");
   return vittf_check_launch();
-}
-
-extern "C" int vittf_block_tail_fx(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g,
-                                   const float* ln2_b, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
-                                   int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out, void* tile_counter,
-                                   void* stream) {
-  if (!attn_out || !w_packed || !proj_b || !ln2_g || !ln2_b || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
-  if (d != D) return VITTF_ERR_INVALID_ARG;
-  if ((ln_g || ln_b || h_out) && !(ln_g && ln_b && h_out)) return VITTF_ERR_INVALID_ARG;
-  return tail_fx_launch(false, attn_out, w_packed, proj_b, ln2_g, ln2_b, b1, b2, x, rows, dtype, ln_g, ln_b, ln_eps, h_out, nullptr,
-                        nullptr, tile_counter, stream);
-}
-
-// ... and the next block's qkv projection of the new rows in the same launch: qkv_out[rows][3 d] = LayerNorm(x_new; ln_g, ln_b) .
-// Wqkv^T + qkv_b, the q third multiplied by log2(e) / 8 (= vittf_gemm(h_out, ..., VITTF_EPI_BIAS_QKV), bit for bit); w_packed is
-// the stream of weights.pack_tail_fx_qkv_weights (this block's proj / fc1 / fc2 and the NEXT block's qkv weight).
-extern "C" int vittf_block_tail_qkv(const void* attn_out, const void* w_packed, const float* proj_b, const float* ln2_g,
-                                    const float* ln2_b, const float* b1, const float* b2, float* x, int64_t rows, int32_t d,
-                                    int32_t dtype, const float* ln_g, const float* ln_b, float ln_eps, void* h_out,
-                                    const float* qkv_b, void* qkv_out, void* tile_counter, void* stream) {
-  if (!attn_out || !w_packed || !proj_b || !ln2_g || !ln2_b || !b1 || !b2 || !x || rows <= 0) return VITTF_ERR_INVALID_ARG;
-  if (!ln_g || !ln_b || !h_out || !qkv_b || !qkv_out) return VITTF_ERR_INVALID_ARG;
-  if (d != D) return VITTF_ERR_INVALID_ARG;
-  return tail_fx_launch(true, attn_out, w_packed, proj_b, ln2_g, ln2_b, b1, b2, x, rows, dtype, ln_g, ln_b, ln_eps, h_out, qkv_b,
-                        qkv_out, tile_counter, stream);
 }

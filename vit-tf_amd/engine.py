@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .weights import arch_of, fold_patch_embed, interpolate_pos_embed, pack_block_tail_weights, pack_mlp_weights
+from .weights import arch_of, fold_patch_embed, interpolate_pos_embed, pack_block_tail_weights, pack_row_images
 
 _TORCH_DT = {_lib.BF16: torch.bfloat16, _lib.FP16: torch.float16}
 
@@ -33,9 +33,11 @@ class HipViT:
     type, infer.py:309; meets the 1e-3 parity bound against the fp32 CPU path) or 'bf16' (opt-in: 8-bit mantissa,
     2.4e-3 .. 3.9e-3 against the CPU path).  attention: '16bit' (default) or 'fp8' -- BASELINE configs[3]'s fp8 MFMA
     attention path (e4m3 operands on the block-scaled matrix instruction; ~3e-2 on the features: opt-in).
+    fused_tail=False: ViT-S without the packed weight streams (the block tail and the activation-stationary qkv GEMM): the GEMM
+    launches every other width uses; flags: _lib.CFG_* bits (vittf_vit_config.flags), the slower alternatives the tests also run.
     """
 
-    def __init__(self, state_dict, arch='vits8', dtype='fp16', device=None, fused_mlp=None, attention='16bit', fused_tail=None):
+    def __init__(self, state_dict, arch='vits8', dtype='fp16', device=None, attention='16bit', fused_tail=True, flags=0):
         self.lib = _lib.require_device()
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         dim, depth, heads, patch = arch_of(arch)
@@ -48,7 +50,7 @@ class HipViT:
         if attention not in ('16bit', 'fp8'):
             raise ValueError(f"attention must be '16bit' or 'fp8', got {attention!r}")
         self.attention = attention
-        self.cfg = _lib.VitConfig(dim, depth, heads, patch, self.dtype_id, 1e-6, 1 if attention == 'fp8' else 0)
+        self.cfg = _lib.VitConfig(dim, depth, heads, patch, self.dtype_id, 1e-6, 1 if attention == 'fp8' else 0, int(flags))
 
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         h16 = _TORCH_DT[self.dtype_id]
@@ -68,19 +70,12 @@ class HipViT:
             'ln2_g': stack('blocks.{}.norm2.weight', torch.float32), 'ln2_b': stack('blocks.{}.norm2.bias', torch.float32),
         }
         ptrs = {k: v.data_ptr() for k, v in self._t.items()}
-        ptrs['mlp_packed'] = ptrs['tail_packed'] = None
-        import os
-        if fused_tail is None:                  # D = 384: everything behind the attention of a block in one launch (csrc/mlp.hip)
-            fused_tail = (os.environ.get('VITTF_FUSED_TAIL', '1') == '1' and os.environ.get('VITTF_FUSED_MLP', '1') == '1'
-                          and fused_mlp is not False)
-        if fused_mlp is None:                   # ... or at least fc1 -> GELU -> fc2 (+ LayerNorm) of it
-            fused_mlp = os.environ.get('VITTF_FUSED_MLP', '1') == '1'
-        if fused_tail and dim == 384:          # the kernel's register budget is sized for ViT-S
+        ptrs['tail_packed'] = ptrs['qkv_packed'] = None
+        if fused_tail and dim == 384:          # the kernels' register budgets are sized for ViT-S
             self._t['tail_packed'] = pack_block_tail_weights(self._t['proj_w'], self._t['fc1_w'], self._t['fc2_w'])
+            self._t['qkv_packed'] = pack_row_images(self._t['qkv_w'])
             ptrs['tail_packed'] = self._t['tail_packed'].data_ptr()
-        elif fused_mlp and dim == 384:
-            self._t['mlp_packed'] = pack_mlp_weights(self._t['fc1_w'], self._t['fc2_w'])
-            ptrs['mlp_packed'] = self._t['mlp_packed'].data_ptr()
+            ptrs['qkv_packed'] = self._t['qkv_packed'].data_ptr()
         self.weights = _lib.VitWeights(**ptrs)
         self._cls = sd['cls_token'].reshape(1, 1, dim)
         self._pos = sd['pos_embed']
@@ -105,27 +100,24 @@ class HipViT:
             self._pos_cache[key] = (_lib.PosEmbed(cls0.data_ptr(), patch.data_ptr()), cls0, patch)
         return self._pos_cache[key]
 
-    def workspace(self, batch, tokens, lane=0):
-        """Workspace of stream lane `lane` (each concurrently running batch needs its own)."""
+    def workspace(self, batch, tokens):
+        """The engine's workspace for `batch` slices of `tokens` tokens (grown on demand, kept)."""
         need = self.lib.vittf_vit_workspace_bytes(C.byref(self.cfg), batch, tokens)
         if need == 0:
             raise _lib.VittfError('unsupported ViT configuration for the HIP engine')
-        if self._ws is None:
-            self._ws = {}
-        ws = self._ws.get(lane)
-        if ws is None or ws.numel() < need:
-            self._ws[lane] = None
-            ws = self._ws[lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return ws
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
 
-    def k_features(self, view, slice0, batch, out, part=1, lane=0):
+    def k_features(self, view, slice0, batch, out, part=1):
         """Run slices [slice0, slice0+batch) of `view` (a _lib.SliceView) through the ViT and write the
         hooked qkv third (`part`: 0 q, 1 k, 2 v) of the patch tokens as fp16 into `out`
         (tensor of >= batch * f0*f1 * D halves)."""
         p = self.patch_size
         tokens = (view.out_rows // p) * (view.out_cols // p) + 1
         pos, _, _ = self.pos_for(view.out_rows, view.out_cols)
-        ws = self.workspace(batch, tokens, lane)
+        ws = self.workspace(batch, tokens)
         assert out.dtype == torch.float16 and out.is_contiguous() and out.numel() >= batch * (tokens - 1) * self.embed_dim
         rc = self.lib.vittf_vit_k_features(C.byref(self.cfg), C.byref(self.weights), C.byref(pos), C.byref(view),
                                            slice0, batch, part, _lib.ptr(out), _lib.ptr(ws), ws.numel(),

@@ -50,12 +50,6 @@ def engine_batch_for(tokens, embed_dim, requested=None):
     return default
 
 
-# Batches of slices are independent, so consecutive batches can go round-robin onto several HIP streams (each with
-# its own workspace): the VALU/MFMA-bound attention of one batch then overlaps the HBM-bound LayerNorm / GEMM
-# epilogues of another and covers the under-filled last wave of workgroups of every launch.  Measured +5.9 % slices/s
-# with 2 lanes (r01k: 1978 against 1867); the default stays 1 so that per-kernel launch durations (bench.py's roofline leg, rocprof)
-# are those of the kernel alone.
-STREAM_LANES = int(__import__('os').environ.get('VITTF_STREAM_LANES', '1'))
 PARTS = {'q': 0, 'k': 1, 'v': 2}
 # VITTF_DIST_FORCE=1: run the slab exchange even when the process group has ONE rank (the collective then moves nothing, but
 # every call of the multi-rank path -- the in-place all_gather_into_tensor, its deferred wait -- executes on the backend)
@@ -132,32 +126,9 @@ def k_slices(model, dvol, axis, im_sizes, s0, s1, engine_batch=None, part=1, out
         out = torch.empty((n, f0 * f1, model.embed_dim), dtype=torch.float16, device=model.device)
     view = dvol.view(axis, im_sizes)
     flat = out.view(-1)
-    nbatches = -(-n // engine_batch)
-    lanes = max(1, min(STREAM_LANES, nbatches))
-    if lanes == 1:
-        for b0 in range(0, n, engine_batch):
-            model.k_features(view, s0 + b0, min(engine_batch, n - b0), flat[b0 * per:], part)
-        return out
-    main = torch.cuda.current_stream(model.device)
-    streams = _lane_streams(model.device, lanes)
-    for st in streams:
-        st.wait_stream(main)                      # the volume / min-max / earlier use of `out` are ready
-    for i, b0 in enumerate(range(0, n, engine_batch)):
-        with torch.cuda.stream(streams[i % lanes]):
-            model.k_features(view, s0 + b0, min(engine_batch, n - b0), flat[b0 * per:], part, lane=i % lanes)
-    for st in streams:
-        main.wait_stream(st)
+    for b0 in range(0, n, engine_batch):
+        model.k_features(view, s0 + b0, min(engine_batch, n - b0), flat[b0 * per:], part)
     return out
-
-
-_LANE_STREAMS = {}
-
-
-def _lane_streams(device, lanes):
-    key = (str(device), lanes)
-    if key not in _LANE_STREAMS:
-        _LANE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(lanes)]
-    return _LANE_STREAMS[key]
 
 
 class HipOps:

@@ -209,22 +209,18 @@ def _pack_row_images(w):
     return w[:, rows.expand(units, 6, 256, 8), cols.expand(units, 6, 256, 8)].reshape(L, units, -1)
 
 
+def pack_row_images(w):
+    """A K = 384 weight [L, N, 384] (N a multiple of 32) as the stream of 24 KB LDS images of vittf_gemm_as (csrc/gemm_as.hip):
+    image u = rows 32 u .. + 31, natural k order -> [L, N / 32, 12288]."""
+    return _pack_row_images(w).contiguous()
+
+
 def norm2_register_order():
     """Column of x held at fc1 input position 16 s + 8 h + e when norm2 is computed in the block-tail kernel's accumulator
     registers (csrc/mlp.hip): 32 (s >> 1) + 16 (s & 1) + 8 (e >> 2) + 4 h + (e & 3)."""
     p = torch.arange(384)
     s_, h, e = p >> 4, (p >> 3) & 1, p & 7
     return 32 * (s_ >> 1) + 16 * (s_ & 1) + 8 * (e >> 2) + 4 * h + (e & 3)
-
-
-def pack_block_tail_weights(wp, w1, w2):
-    """proj / fc1 / fc2 weights of L blocks -> the stream of the block-tail kernel (vittf_block_tail): per block 12 images
-    of the projection (Wp rows 32 ot .. + 31 over the 384 attention outputs), then the MLP's 96 with fc1's input dim in the
-    order norm2 leaves its values in the registers.  wp: [L, D, D], w1: [L, 4D, D], w2: [L, D, 4D] -> [L, 108, 12288]."""
-    L, d, d2 = wp.shape
-    assert d == 384 and d2 == 384
-    order = norm2_register_order().to(w1.device)
-    return torch.cat([_pack_row_images(wp), pack_mlp_weights(w1[:, :, order], w2)], dim=1).contiguous()
 
 
 def _mlp_images(w1, w2):
@@ -249,20 +245,6 @@ def _mlp_images(w1, w2):
     return img1, img2
 
 
-def pack_mlp_weights(w1, w2):
-    """fc1 / fc2 weights of L blocks -> the stream the fused MLP kernel (csrc/mlp.hip) consumes: per block 96 images of
-    24 KB in consumption order W1(0), W1(1), W1(2), W2(0), W1(3), W2(1), .., W1(47), W2(45), W2(46), W2(47) (_mlp_images), so
-    that every LDS-DMA piece is 1 KB of contiguous memory.
-    w1: [L, 4D, D], w2: [L, D, 4D] (16-bit, any device).  Returns [L, 96, 12288] of the same dtype."""
-    img1, img2 = _mlp_images(w1, w2)
-    units = img1.shape[1]
-    order = [('1', 0), ('1', 1)]
-    for k in range(2, units):
-        order += [('1', k), ('2', k - 2)]
-    order += [('2', units - 2), ('2', units - 1)]
-    return torch.stack([(img1 if t == '1' else img2)[:, u] for t, u in order], dim=1).contiguous()
-
-
 TAIL_FX_PSTEPS, TAIL_FX_MSTEPS, TAIL_FX_LAG = 12, 100, 4
 
 
@@ -282,8 +264,8 @@ def _pack_proj_kmajor(wp):
     return wp[:, rows.expand(12, 6, 256, 8), cols.expand(12, 6, 256, 8)].reshape(L, 12, -1)
 
 
-def pack_tail_fx_weights(wp, w1, w2):
-    """proj / fc1 / fc2 weights of L blocks -> the stream of the role-split block-tail kernel (csrc/tail_fx.hip): per block
+def pack_block_tail_weights(wp, w1, w2):
+    """proj / fc1 / fc2 weights of L blocks -> the stream of the block-tail kernel (vittf_block_tail, csrc/tail_fx.hip): per block
     12 projection steps of 24 KB (k steps 2 p, 2 p + 1 of all output tiles, K-major: _pack_proj_kmajor), then 100 main steps =
     [ W1(m >> 1) k half m & 1 | W2((m - 4) >> 1) output-tile half (m - 4) & 1 ] (zeros where a role has no work: the first four
     W2 halves, the last four W1 halves); fc1's input dim in the order norm2 leaves its values in the registers.
@@ -301,45 +283,6 @@ def pack_tail_fx_weights(wp, w1, w2):
         b = img2[:, m2 >> 1, (m2 & 1) * half:(m2 & 1) * half + half] if m2 >= 0 else zero
         steps.append(torch.cat([a, b], dim=-1))
     return torch.cat([_pack_proj_kmajor(wp), torch.stack(steps, dim=1)], dim=1).contiguous()
-
-
-def _pack_proj_kstep_halves(wp):
-    """[L, 384, 384] -> [L, 24, 6144]: the projection one k step at a time: fragment f (0 .. 11; sub-image f >> 2, chunk pair
-    f & 3 of the X half of a step) = Wp[32 f + r][16 p + 8 h + e]."""
-    L, n, d = wp.shape
-    assert n == 384 and d == 384
-    dev = wp.device
-    r, c = (t.to(dev) for t in _tile_pos_tables())
-    e = torch.arange(8, device=dev).view(1, 1, 1, -1)
-    s3 = torch.arange(3, device=dev).view(1, -1, 1, 1)
-    p = torch.arange(24, device=dev).view(-1, 1, 1, 1)
-    f = 4 * s3 + (c.view(1, 1, -1, 1) >> 1)                                 # [1, 3, 256, 1]
-    rows = 32 * f + r.view(1, 1, -1, 1)
-    cols = 16 * p + 8 * (c.view(1, 1, -1, 1) & 1) + e                        # [24, 1, 256, 8]
-    return wp[:, rows.expand(24, 3, 256, 8), cols.expand(24, 3, 256, 8)].reshape(L, 24, -1)
-
-
-TAIL_FXQ_BSTEPS = 72
-
-
-def pack_tail_fx_qkv_weights(wp, w1, w2, wqkv_next):
-    """The stream of vittf_block_tail_qkv (csrc/tail_fx_qkv.inc): per block 72 boundary steps of 24 KB = [ k half s & 1 of the
-    NEXT block's qkv rows 32 (s >> 1) .. (natural k order: the sums of the stand-alone GEMM) | for s = 12 .. 35 this block's
-    projection k step s - 12, zeros elsewhere ], then the 100 main steps of pack_tail_fx_weights.
-    wp: [L, D, D], w1: [L, 4D, D], w2: [L, D, 4D], wqkv_next: [L, 3D, D] (block l + 1's weight at index l) -> [L, 172, 12288]."""
-    L, d, d2 = wp.shape
-    assert d == 384 and d2 == 384 and tuple(wqkv_next.shape) == (L, 3 * d, d)
-    imgq = _pack_row_images(wqkv_next)                      # [L, 36, 12288]
-    half = imgq.shape[-1] // 2
-    pj = _pack_proj_kstep_halves(wp)                        # [L, 24, 6144]
-    zero = torch.zeros_like(pj[:, 0])
-    steps = []
-    for s_ in range(TAIL_FXQ_BSTEPS):
-        a = imgq[:, s_ >> 1, (s_ & 1) * half:(s_ & 1) * half + half]
-        b = pj[:, s_ - 12] if 12 <= s_ < 36 else zero
-        steps.append(torch.cat([a, b], dim=-1))
-    main = pack_tail_fx_weights(wp, w1, w2)[:, TAIL_FX_PSTEPS:]
-    return torch.cat([torch.stack(steps, dim=1), main], dim=1).contiguous()
 
 
 def permute_fc2_hidden(w2):
