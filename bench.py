@@ -83,6 +83,76 @@ def vit_flops(n_tokens, dim, depth, patch):
     }
 
 
+def extra_configs(vt, torch, dvol, vol, feats, dev, dtype):
+    """BASELINE configs[3] (ViT-B/8, 16-bit and fp8 attention), configs[4] (5 x 1024-query similarity + the bilateral solver) and the
+    fos-128 preset of sub/infer_and_merge.sh on the SAME 512^3 volume, behind the contract's timed region: a short run each,
+    with the dominant kernel class priced against its own peak.  Informative objects on the JSON line, never `value`."""
+    out = {}
+    total_slices = sum(dvol.shape)
+
+    def extractor(arch, attention, fos, steps):
+        dim, depth, heads, patch = vt.ARCHS[arch]
+        model = vt.HipViT(vt.synthetic_state_dict(arch, 0), arch, dtype, device=dev, attention=attention)
+        im, fo = vt.sizing(dvol.shape, fos, 8)
+        ntok = (im[0] // 8) * (im[1] // 8) + 1
+        eb = vt.extract.engine_batch_for(ntok, dim)
+        run = lambda: vt.feature_volume(None, model, fos, 'all', eb, dvol=dvol)
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+        vt._lib.profiler_enable(True)
+        run()
+        torch.cuda.synchronize()
+        prof = vt._lib.profiler_collect()
+        vt._lib.profiler_enable(False)
+        fl = vit_flops(ntok, dim, depth, patch)
+        if prof['mlp'][1] > 0:
+            fl['mlp'] = fl.pop('gemm_fc1') + fl.pop('gemm_fc2') + fl.pop('gemm_proj')
+        fl = {k: v * total_slices for k, v in fl.items()}
+        tf = {k: round(fl[k] / (prof[k][0] * 1e-3) / 1e12, 1) for k in fl if prof[k][0] > 0}
+        dom = max(tf, key=lambda k: prof[k][0])
+        peak = PEAK_TFLOPS['fp8' if (dom == 'attention' and attention == 'fp8') else dtype]
+        del model
+        torch.cuda.empty_cache()
+        return {'value': round(total_slices / el, 1), 'unit': 'slices/s', 'ms_per_step': round(el * 1e3, 1), 'steps': steps, 'tokens': ntok,
+                'engine_batch': eb, 'attention': attention, 'dominant_kernel': dom, 'dominant_share': round(prof[dom][0] / sum(v[0] for v in prof.values()), 3),
+                'frac': round(tf[dom] / peak, 4), 'peak_tflops': peak, 'kernel_tflops': tf,
+                'whole_vit_tflops': round(sum(fl.values()) / (sum(v[0] for k, v in prof.items() if k != 'similarity') * 1e-3) / 1e12, 1)}
+    out['config3_vitb8'] = {'16bit': extractor('vitb8', '16bit', FOS, 2), 'fp8': extractor('vitb8', 'fp8', FOS, 2),
+                            'note': 'BASELINE configs[3] on one GPU: ViT-B/8 (D = 768) feature volume of the same 512^3 volume'}
+    out['fos128'] = dict(extractor('vits8', '16bit', 128, 1), note='sub/infer_and_merge.sh preset: 1024 x 1024 slices, N = 16385')
+    # configs[4]: five classes of 1024 annotations each on the metric's feature volume (seeded voxel coordinates)
+    g = torch.Generator().manual_seed(4)
+    ann = {f'c{i}': torch.stack([torch.randint(0, n, (1024,), generator=g) for n in dvol.shape], dim=1) for i in range(5)}
+    vt.compute_similarities(vol, feats, ann, keep_on_device=True)
+    torch.cuda.synchronize()
+    vt._lib.profiler_enable(True, classes=['similarity'])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        vt.compute_similarities(vol, feats, ann, keep_on_device=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    k_ms, k_n = vt._lib.profiler_collect()['similarity']
+    vt._lib.profiler_enable(False)
+    nvox, dim = feats[0].numel(), feats.shape[0]
+    fl = 2.0 * nvox * dim * 5120 * 2            # queries enter as fp16 hi + lo halves: two matrix products
+    t0 = time.perf_counter()
+    vt.compute_similarities(vol, feats, ann, keep_on_device=True, bilateral_solver=True)
+    torch.cuda.synchronize()
+    bls_ms = (time.perf_counter() - t0) * 1e3
+    out['config4_1024q'] = {'queries': 5120, 'ms': round(ms, 3), 'mvoxel_sim_per_s': round(nvox * 5120 / 1e6 / (ms * 1e-3), 1),
+                            'kernel': vt._lib.kernel_name('similarity'), 'kernel_ms': round(k_ms / max(1, k_n), 3),
+                            'kernel_tflops': round(fl / (k_ms / max(1, k_n) * 1e-3) / 1e12, 1), 'frac': round(fl / (k_ms / max(1, k_n) * 1e-3) / 1e12 / PEAK_TFLOPS['fp16'], 4),
+                            'with_bilateral_solver_ms': round(bls_ms, 2),
+                            'note': 'BASELINE configs[4]: 5 x 1024 annotations on the (384, 64, 64, 64) volume, maps left on the GPU; frac: hi + lo '
+                                    'query halves = two matrix products, against the fp16 MFMA peak; the bilateral-solver call includes its first-call setup'}
+    return out
+
+
 def make_workload(name, vt):
     """(volume fp16, label uint8, description) -- seeded, generated on the host before timing."""
     if name == '256':
@@ -433,6 +503,9 @@ def main():
                                    'maps_bytes_to_host over PCIe); ms_maps_on_device: keep_on_device=True'},
         }
         out['e2e_incl_upload'] = e2e
+        if (world == 1 and args.arch == 'vits8' and args.attention == '16bit' and args.fos == FOS and args.workload == '512'
+                and os.environ.get('VITTF_BENCH_EXTRAS', '1') == '1'):
+            out.update(extra_configs(vt, torch, dvol, vol, feats, dev, args.dtype))
         if world == 1 and args.cpu_slices > 0:
             out['cpu_baseline'] = cpu_baseline(sd, vol, args.cpu_slices, im_sz, args.arch, feats.cpu(), ann, tuple(dvol.shape))
         else:

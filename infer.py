@@ -254,7 +254,8 @@ def main(argv=None):
     parser.add_argument('--dino2-model', type=str, choices=dino2_archs, default=None, help='DINOv2 variant (not available offline)')
     parser.add_argument('--slice-along', type=str, choices=['x', 'y', 'z', 'all'], default='all',
                         help='Along which axis to slice volume, as it is fed slice-wise to DINO')
-    parser.add_argument('--batch-size', type=int, default=1, help='accepted for compatibility; the engine batches slices itself')
+    parser.add_argument('--batch-size', type=int, default=1, help='a LOWER bound on the slices per engine call (the engine sizes its own calls: 256 x 4097 / tokens by '
+                        'default); the memory knob is $VITTF_ENGINE_BATCH')
     parser.add_argument('--feature-output-size', type=int, default=64,
                         help='Produces a features map with aspect ratio of input volume with this value as y resolution. Only if --slice-along ALL')
     parser.add_argument('--cpu', action='store_true', help='Use CPU only (not available in the MI355X build)')

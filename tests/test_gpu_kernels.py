@@ -69,6 +69,49 @@ def test_gemm_bias_and_gelu(gpu, dt, rows, n, k):
         assert ((got[:rows] - refv).abs() <= EPS[dt] * refv.abs() * 1.01 + 3e-5 * k ** 0.5).all()
 
 
+@pytest.mark.parametrize('case', ['bias', 'gelu', 'residual', 'kfeat'])
+def test_gemm_pp_many_tiles_per_workgroup_same_bits_as_one_tile_launches(gpu, case):
+    """csrc/gemm_pp.hip is persistent: with more 256 x 256 tiles than CUs a workgroup runs several tiles back to back -- the ring
+    never drains, the next tile's first stages are requested under the counted waits of this one, the epilogue's stores stay in
+    flight under the next K loop.  Every other gemm_pp test shape has fewer tiles than an MI355X has CUs, so this path is checked
+    here per element: one launch with 303 .. 2709 tiles against the SAME rows computed by launches of at most 255 tiles (one tile
+    per workgroup), bit for bit, plus fp64."""
+    lib = _lib.load()
+    dt = 'fp16'
+    tokens = 4097
+    rows, n, k, epi, chunk = {'bias': (256 * 300 + 33, 2304, 768, _lib.EPI_BIAS, 256 * 28),
+                              'gelu': (256 * 40, 3072, 768, _lib.EPI_BIAS_GELU, 256 * 21),
+                              'residual': (256 * 100 + 7, 768, 3072, _lib.EPI_BIAS_RESIDUAL, 256 * 85),
+                              'kfeat': (20 * tokens, 768, 768, _lib.EPI_KFEAT, 5 * tokens)}[case]
+    assert (rows + 255) // 256 * (n // 256) > 256 + 32 and (chunk + 255) // 256 * (n // 256) <= 255
+    g = gen(rows + n)
+    a = torch.randn(rows, k, generator=g).to(TDT[dt]).to(gpu)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(TDT[dt]).to(gpu)
+    bias = (0.2 * torch.randn(n, generator=g)).to(gpu)
+    out_rows = rows - rows // tokens if case == 'kfeat' else rows
+    odt = torch.float32 if case == 'residual' else (torch.float16 if case == 'kfeat' else TDT[dt])
+    x0 = (torch.randn(out_rows + 3, n, generator=g) * 4).to(odt).to(gpu) if case == 'residual' else torch.full((out_rows + 3, n), 7.0, dtype=odt, device=gpu)
+    big = x0.clone()
+    _lib.check(lib.vittf_gemm(_lib.ptr(a), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(big), rows, n, k, epi, tokens, _lib.DTYPES[dt], _lib.stream_ptr()))
+    small = x0.clone()
+    for r0 in range(0, rows, chunk):
+        r1 = min(rows, r0 + chunk)
+        o0 = r0 - r0 // tokens if case == 'kfeat' else r0
+        _lib.check(lib.vittf_gemm(_lib.ptr(a[r0:]), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(small[o0:]), r1 - r0, n, k, epi, tokens, _lib.DTYPES[dt],
+                                  _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(big[out_rows:], x0[out_rows:]), 'wrote past the last row'
+    assert torch.equal(big, small), f'{int((big != small).sum())} values differ between one launch and one-tile-per-workgroup launches'
+    ref = a.double() @ w.double().t() + bias.double()
+    if case == 'gelu':
+        ref = F.gelu(ref)
+    if case == 'kfeat':
+        ref = ref.view(20, tokens, n)[:, 1:].reshape(-1, n)
+    if case == 'residual':
+        ref = ref + x0[:rows].double()
+    assert rel_fro(big[:out_rows].double(), ref) <= EPS[dt]
+
+
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('rows,n,k', [(3, 128, 64), (515, 384, 384), (200, 384, 1536), (33000, 384, 384), (1030, 384, 1536), (256, 384, 64),
                                        (515, 768, 768), (200, 768, 3072), (33000, 768, 768), (129, 768, 64)])

@@ -353,8 +353,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
             const int64_t total8 = (int64_t)f8.batch * f8.heads * f8.np;
             const auto r8 = __builtin_amdgcn_make_buffer_rsrc(third == 0 ? f8.q8 : f8.k8, 0, (int)(unsigned)(total8 * 64), 0x00020000);
             const auto rsc = __builtin_amdgcn_make_buffer_rsrc(third == 0 ? f8.qs : f8.ks, 0, (int)(unsigned)(total8 * 2), 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(pk8, r8, ok ? (int)(unsigned)(rowi * 64 + pos) : -1, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(127 + ex), rsc, (ok && (c16 & 1) == 0) ? (int)(unsigned)(rowi * 2 + (dim >> 5)) : -1, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(pk8, r8, ok ? (int)(unsigned)(rowi * 64 + pos) : (int)0x80000000u, 0, 0);      // (dropped rows: out of range without wrapping)
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(127 + ex), rsc, (ok && (c16 & 1) == 0) ? (int)(unsigned)(rowi * 2 + (dim >> 5)) : (int)0x80000000u, 0, 0);
           } else {
             // v: 16-bit values into the qkv buffer's v third; its absolute maximum per (slice, head) on the way out
             if (tokens < PBM) {          // (tiny slices: a tile holds more than two of them -- one atomic per thread and row)
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const unsigned short* _
               const int64_t b = m / tokens;
               const int tok = (int)(m - b * tokens);
               const int64_t orow = b * (tokens - 1) + tok - 1;
-              const unsigned off = (m < rows && tok != 0) ? (unsigned)((orow * n + n0 + 4 * ch) * 2) : 0xffffffffu;
+              const unsigned off = (m < rows && tok != 0) ? (unsigned)((orow * n + n0 + 4 * ch) * 2) : 0x80000000u;      // (dropped rows: an offset whose 16 bytes cannot wrap into the buffer)
               __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (int)off, 0, PV_ST_AUX);
             } else {
 #pragma unroll

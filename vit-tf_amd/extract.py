@@ -44,7 +44,9 @@ def engine_batch_for(tokens, embed_dim, requested=None):
         return max(1, int(env))
     default = max(1, min(DEFAULT_ENGINE_BATCH, DEFAULT_ENGINE_BATCH * 4097 // int(tokens)))
     if isinstance(requested, AtLeast):
-        return max(int(requested), default)
+        # (never above 4 x the default: the widest buffers of a call -- rows x 4 D 16-bit values, the fp8 operand rows -- are
+        #  addressed with 32-bit offsets)
+        return min(max(int(requested), default), 4 * default)
     if requested:
         return max(1, int(requested))
     return default
