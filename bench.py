@@ -475,6 +475,24 @@ def main():
                                  '(2 D) + fp32 residual in and out (8 D) + 16-bit LayerNorm output (2 D); the 2.65 MB of weights every '
                                  'workgroup re-reads come from L2 / the Infinity Cache; traffic: profiles/pmc_block_tail.json'}
 
+    # the third: the qkv projection of every block but the first, activation-stationary (csrc/gemm_as.hip).  2.65 GFLOP per MB it
+    # must move: priced on both roofs.
+    roofline_qkv = None
+    if args.arch == 'vits8' and prof.get('gemm_qkv', (0, 0))[1] > 0 and prof['gemm_qkv'][0] > 0:
+        q_ms, q_n = prof['gemm_qkv']
+        q_rows = (args.engine_batch if my_slices >= args.engine_batch else my_slices) * n_tokens
+        q_bytes = int(q_rows * (dim * 2 + 3 * dim * 2))
+        q_ach = flops['gemm_qkv'] / (q_ms * 1e-3) / 1e12
+        roofline_qkv = {'bound': 'mfma', 'achieved': round(q_ach, 2), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
+                        'frac': round(q_ach / PEAK_TFLOPS[args.dtype], 4),
+                        'traffic': pmc_traffic('gemm_qkv', args.engine_batch if my_slices >= args.engine_batch else my_slices,
+                                               tokens=n_tokens, features=dim),
+                        'kernel': kernels['gemm_qkv'], 'launches': int(q_n), 'avg_launch_ms': round(q_ms / q_n, 4),
+                        'flop_per_launch': flops['gemm_qkv'] / q_n, 'algorithmic_bytes_per_launch': q_bytes,
+                        'hbm_frac_at_algorithmic_bytes': round(q_bytes / (q_ms / q_n * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        'note': 'events around its launches in one extra untimed step; algorithmic bytes per token row: LayerNorm output in '
+                                '(2 D) + q, k, v out (6 D); traffic: profiles/pmc_gemm_qkv.json'}
+
     if rank == 0:
         out = {
             'metric': f'slices/sec ({"ViT-S/8" if args.arch == "vits8" else "ViT-B/8"}, {args.workload}^3 vol: feature volume + '
@@ -493,6 +511,7 @@ def main():
             'roofline': roofline,
             'roofline_similarity': roofline_sim,
             'roofline_block_tail': roofline_tail,
+            'roofline_gemm_qkv': roofline_qkv,
             'similarity': {'ms': round(sim_ms, 3), 'queries': N_QUERIES,
                            'mvoxel_sim_per_s': round(nvox * N_QUERIES / 1e6 / (sim_ms * 1e-3), 1),
                            'mvoxel_per_s': round(nvox / 1e6 / (sim_ms * 1e-3), 1),

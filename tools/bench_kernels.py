@@ -36,7 +36,7 @@ def timeit(fn, reps=10, warm=3, settle_s=float(os.environ.get('SETTLE_S', '0.4')
 
 
 def main():
-    what = set(sys.argv[1:]) or {'attn', 'gemm', 'mlp', 'ln', 'sim'}
+    what = set(sys.argv[1:]) or {'attn', 'gemm', 'qkv', 'tail', 'ln', 'sim'}
     lib = _lib.load()
     dev = torch.device('cuda', 0)
     dt = os.environ.get('DT', 'fp16')
@@ -142,20 +142,18 @@ def main():
             t0 = time.perf_counter(); ref = osmp.surface_shell(lab.numpy() == 1); cpu_s = time.perf_counter() - t0
             same = bool((vt.samplers.surface_shell(dl, 4, class_id=1).cpu().numpy().astype(bool) == ref).all())
             print(f'  scipy binary_erosion x2 + xor on the host: {cpu_s:.1f} s; identical: {same}')
-    if 'mlp' in what:
+    if 'qkv' in what:      # the activation-stationary qkv projection (csrc/gemm_as.hip), K = 384, N = 1152
         hh = torch.randn(rows, d, generator=g).to(TDT[dt]).to(dev)
-        w1 = (torch.randn(4 * d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(dev)
-        w2 = (torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5).to(TDT[dt]).to(dev)
-        wpk = vt.weights.pack_mlp_weights(w1[None], w2[None])[0].contiguous()
-        b1 = torch.randn(4 * d, generator=g).to(dev); b2 = torch.randn(d, generator=g).to(dev)
-        x = torch.zeros(rows, d, device=dev)
-        lg = torch.ones(d, device=dev); lb = torch.zeros(d, device=dev)
-        hn = torch.empty(rows, d, dtype=TDT[dt], device=dev)
+        wq = (torch.randn(3 * d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(dev)
+        wpk = vt.weights.pack_row_images(wq[None])[0].contiguous()
+        bq = torch.randn(3 * d, generator=g).to(dev)
+        out = torch.empty(rows, 3 * d, dtype=TDT[dt], device=dev)
         ctr = torch.zeros(1, dtype=torch.int32, device=dev)
-        ms = timeit(lambda: _lib.check(lib.vittf_mlp_fused(_lib.ptr(hh), _lib.ptr(wpk), _lib.ptr(b1), _lib.ptr(b2), _lib.ptr(x), rows, d,
-                                                            _lib.DTYPES[dt], _lib.ptr(lg), _lib.ptr(lb), 1e-6, _lib.ptr(hn), _lib.ptr(ctr), _lib.stream_ptr())))
-        fl = 4 * rows * d * 4 * d
-        print(f'fused mlp + ln [{rows}x{d}]: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({ms * 32 / batch:.4f} ms per 32 slices)')
+        ms = timeit(lambda: _lib.check(lib.vittf_gemm_as(_lib.ptr(hh), _lib.ptr(wpk), _lib.ptr(bq), _lib.ptr(out), rows, 3 * d, d,
+                                                          _lib.EPI_BIAS_QKV, _lib.DTYPES[dt], _lib.ptr(ctr), _lib.stream_ptr())))
+        fl = 2 * rows * d * 3 * d
+        print(f'qkv projection [{rows}x{d}] x [{3 * d}x{d}]^T: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  '
+              f'({(rows * d * 2 + rows * 3 * d * 2) / ms / 1e6:.0f} GB/s algorithmic)')
     if 'tail' in what:
         aa = torch.randn(rows, d, generator=g).to(TDT[dt]).to(dev)
         wp = (torch.randn(d, d, generator=g) / d ** 0.5).to(TDT[dt]).to(dev)

@@ -19,14 +19,13 @@ for s in "$@"; do
   case $s in
     allgpu)   # what the driver runs at round end: the whole -m gpu suite as ONE process (900 s limit there)
               step test_all 900 python -m pytest tests -x -q -m gpu -s --durations=25 -p no:cacheprovider ;;
-    fos128)   VITTF_BENCH_OVERLAP=0 step bench512_fos128 900 python bench.py --fos 128 --steps 2 --warmup 1 --cpu-slices 0 ;;
+    fos128)   step bench512_fos128 900 python bench.py --fos 128 --steps 2 --warmup 1 --cpu-slices 0 ;;
     kernels)  step test_kernels 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider ;;
     pipeline) step test_pipeline 900 python -m pytest tests/test_gpu_pipeline.py -q -m gpu -s -p no:cacheprovider ;;
     smoke)    step smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)    step bench 900 python bench.py --steps 2 --warmup 1 ;;
     bench64)  step bench64 600 python bench.py --steps 1 --warmup 1 --workload 64 --cpu-slices 0 ;;
     prof)     cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
-              export VITTF_BENCH_OVERLAP=0   # the profile is of the contract measurement (one lane), not of the two-lane leg
               step rocprof 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 1 --warmup 1 --workload 64 --cpu-slices 0 ;;
     attn)     step test_attn 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider -k "attention or resize or widened or empty_class or single_annotation" ;;
     fullsize) step test_fullsize 1100 python -m pytest tests/test_gpu_fullsize.py -q -m gpu -s -p no:cacheprovider ;;
@@ -43,19 +42,22 @@ for s in "$@"; do
     pmctail)  export BATCH=256 DT=fp16
               step pmc_tail 900 bash tools/pmc_attn.sh tail
               unset BATCH
-              python tools/pmc_json.py block_tail $OUT/pmc_tail.log mlp_kernel $OUT/pmc_block_tail.json batch=256 tokens=4097 features=384 > /dev/null ;;
+              python tools/pmc_json.py block_tail $OUT/pmc_tail.log tail_fx_kernel $OUT/pmc_block_tail.json batch=256 tokens=4097 features=384 > /dev/null ;;
+    pmcqkv)   export BATCH=256 DT=fp16
+              step pmc_qkv 900 bash tools/pmc_attn.sh qkv
+              unset BATCH
+              python tools/pmc_json.py gemm_qkv $OUT/pmc_qkv.log gemm_as_kernel $OUT/pmc_gemm_qkv.json batch=256 tokens=4097 features=384 > /dev/null ;;
     fp8)      step test_fp8 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -q -m gpu -s -p no:cacheprovider -k "fp8 or vitb8" ;;
-    benchb)   for a in 16bit fp8; do VITTF_BENCH_OVERLAP=0 step benchb_$a 600 python bench.py --arch vitb8 --workload 64 --attention $a --cpu-slices 0 --steps 2; done ;;
-    benchb512) for a in 16bit fp8; do VITTF_BENCH_OVERLAP=0 step benchb512_$a 600 python bench.py --arch vitb8 --attention $a --cpu-slices 0 --steps 2; done ;;
+    benchb)   for a in 16bit fp8; do step benchb_$a 600 python bench.py --arch vitb8 --workload 64 --attention $a --cpu-slices 0 --steps 2; done ;;
+    benchb512) for a in 16bit fp8; do step benchb512_$a 600 python bench.py --arch vitb8 --attention $a --cpu-slices 0 --steps 2; done ;;
     simmany)  step sim_many 300 python tools/sim_many_profile.py ;;
     simtests) step test_sim 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider -k "similarity or sim or golden or labels or cosine or topk" ;;
     prof8)    cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               SETTLE_S=0.05 step prof8 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof8 -- python tools/bench_kernels.py attn8 ;;
-    benchbatch) for eb in 64 128 256 512; do VITTF_BENCH_OVERLAP=0 step benchbatch_$eb 600 python bench.py --engine-batch $eb --cpu-slices 0 --steps 2; done ;;
-    benchenv) for e in ${BENCHENV:-VITTF_ROWS_WM=1 VITTF_ROWS_WM=2}; do export $e; VITTF_BENCH_OVERLAP=0 step benchenv_${e}_$RANDOM 600 python bench.py --cpu-slices 0 --steps 2; unset ${e%%=*}; done ;;
+    benchbatch) for eb in 64 128 256 512; do step benchbatch_$eb 600 python bench.py --engine-batch $eb --cpu-slices 0 --steps 2; done ;;
     bench512) step bench512 900 python bench.py ;;
     prof512)  cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
-              export VITTF_BENCH_OVERLAP=0
+              export VITTF_BENCH_EXTRAS=0
               step rocprof512 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof512 -- python bench.py --steps 1 --warmup 1 --cpu-slices 0 ;;
     *) echo "unknown step $s" ;;
   esac
