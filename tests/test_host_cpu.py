@@ -255,3 +255,17 @@ def test_block_tail_kernel_register_contract():
         ours = r's_mov_b32 (m0, s\d+|s\d+, m0)'          # lds_dma16_keep, and the prologue's lds_dma16 (saves and restores)
         assert m0 and all(re.fullmatch(ours, l) for l in m0), [l for l in m0 if not re.fullmatch(ours, l)][:5]
         assert 'flat_load' not in asm
+
+
+def test_window_goldens_cover_the_fullsize_tests():
+    """tests/golden/windows512.npz (made by tests/golden/make_window_goldens.py from the CPU oracle) holds every pooled window the
+    full-size GPU tests compare with: fp16, every 4th feature row / column of a (D, 64, 64) window, finite, not constant."""
+    import numpy as np
+    import helpers
+    z = helpers.load_golden(os.path.join(ROOT, 'tests', 'golden'), 'windows512.npz')
+    assert set(z) == {helpers.window_key(*w) for w in helpers.WINDOWS512}
+    n = 64 // helpers.WINDOW_STRIDE
+    for arch, seed, axis, w in helpers.WINDOWS512:
+        a = z[helpers.window_key(arch, seed, axis, w)]
+        assert a.dtype == np.float16 and a.shape == ({'vits8': 384, 'vitb8': 768}[arch], n, n)
+        assert np.isfinite(a).all() and float(a.astype(np.float32).std()) > 1e-3

@@ -3,7 +3,7 @@
 # fragment reads in the K loop, 32 no epilogue, 128 no scheduling fences inside a stage, 512 / 1024 / 2048 the epilogue's
 # 16-bit stores with the plain / sc0 nt / sc0 sc1 cache policy instead of nt), each as its own small shared object under
 # tools/micro/build/ -- never part of libvittf.so.  Variants with bits 1, 4 or 32 compute wrong results by construction.
-# (Bits 2, 8, 16 and 64 belonged to the two-segment forms of the kernel: DESIGN.md section 4.)
+# (Bits 2, 8, 16 and 64 belonged to the two-segment forms of the kernel: LAB_NOTES.md, former DESIGN section 4.)
 #   tools/pp_variants.sh 0 1 2 ...     then on the GPU box: python tools/pp_variants.py
 set -e
 tools=$(cd "$(dirname "$0")" && pwd)

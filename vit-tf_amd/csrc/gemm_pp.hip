@@ -2,7 +2,7 @@
 //     out = epilogue(A[rows][K] . W[N][K]^T + bias[N]),   K % 64 == 0, K >= 768, N % 256 == 0
 //
 // Round 4 (BASELINE configs[3]).  gemm.hip's 128 x 128 x 64 tiles (one stage, four workgroups per CU) run these shapes at
-// 740-870 TFLOP/s.  Earlier forms of this file are in the history with their numbers ("Round 4: the
+// 740-870 TFLOP/s.  Earlier forms of this file are in the history with their numbers (LAB_NOTES.md, former DESIGN section 4, "Round 4: the
 // ViT-B linears": a pipelined 256 x 128 kernel with two workgroups per CU; an 8-wave ping-pong kernel with a load segment
 // and an MFMA segment per K step -- hence the file's name; the same made persistent); timing-only builds of each
 // (tools/pp_variants.sh) said where its time went.  This form:
