@@ -27,6 +27,16 @@
 
 namespace {
 
+// timing-only builds (tools/attn_variants.sh; never in libvittf.so, results wrong by construction): the LDS-DMA of every
+// PP_DMA_EVERY-th tile only (2 = what a 512-row workgroup would issue per query row; a skipped tile's buffer still holds an
+// older tile: finite scores), 0 = the first three tiles only (the ring is filled once)
+#ifndef PP_DMA_EVERY
+#define PP_DMA_EVERY 1
+#endif
+__device__ __forceinline__ constexpr bool pp_dma_on(int t) {
+  return PP_DMA_EVERY == 1 || (PP_DMA_EVERY > 1 ? t % (PP_DMA_EVERY > 1 ? PP_DMA_EVERY : 1) == 0 : t < 3);
+}
+
 constexpr int NBUF = 3;
 constexpr int QT = 256;                  // query rows per workgroup: 4 waves x 2 blocks x 32 rows
 constexpr int KT = ATT_KT;               // keys per tile
@@ -262,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(const unsigned short*
   {                                                                                                 \
     const int so_ = (t_) * tile_stride;                                                             \
     const unsigned dst_ = dma_dst + (bufi_) * BUFB;                                                 \
-    if ((t_) == nt - 1) {                                                                           \
+    if (!pp_dma_on(t_)) {                                                                           \
+    } else if ((t_) == nt - 1) {                                                                         \
       int vk_ = voff_k, vv_ = voff_v;   /* opaque copies: the sums below are formed here, not kept alive through the loop */ \
       asm volatile("" : "+v"(vk_), "+v"(vv_));                                                      \
       _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                            \
@@ -424,6 +435,13 @@ extern "C" int64_t vittf_attention_rescale_count(int32_t reset) {
   }
   return (int64_t)v;
 }
+
+#ifdef PP_STANDALONE      // tools/attn_variants.sh builds this file alone
+int vittf_attention_pp64(const void*, void*, int32_t, int32_t, int32_t, int32_t, hipStream_t);
+extern "C" int vittf_attention_variant(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype, void* st) {
+  return vittf_attention_pp64(qkv, out, batch, tokens, heads, dtype, (hipStream_t)st);
+}
+#endif
 
 // C++ linkage: called by vittf_attention (attention.hip) for q_prescaled = 1
 int vittf_attention_pp64(const void* qkv, void* out, int32_t batch, int32_t tokens, int32_t heads, int32_t dtype, hipStream_t st) {
