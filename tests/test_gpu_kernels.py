@@ -1182,7 +1182,8 @@ def test_qkv_fp8_rows_path(gpu, dt, batch, tokens):
     bias = 0.2 * torch.randn(n, generator=g)
     bias[2 * d:] += 0.5
     ad, wd, bd = a.to(gpu), w.to(gpu), bias.to(gpu)
-    ws = torch.empty(lib.vittf_attention_fp8_workspace_bytes(batch, tokens, heads), dtype=torch.uint8, device=gpu)
+    # (the workspace starts as 0xff bytes: NaN as e4m3, NaN as an E8M0 scale -- what the padded rows of a tile must not keep)
+    ws = torch.full((lib.vittf_attention_fp8_workspace_bytes(batch, tokens, heads),), 0xff, dtype=torch.uint8, device=gpu)
     qkv = torch.full((rows + 2, n), 7.0, dtype=TDT[dt], device=gpu)
     _lib.check(lib.vittf_gemm_qkv_fp8(_lib.ptr(ad), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(qkv), rows, n, k, tokens, heads,
                                       _lib.DTYPES[dt], _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
@@ -1215,6 +1216,9 @@ def test_qkv_fp8_rows_path(gpu, dt, batch, tokens):
     for part, (o8, osc) in enumerate(((off_q, off_qs), (off_q + per, off_qs + sc_bytes))):
         # a stored row is [d 0-15 | d 32-47 | d 16-31 | d 48-63]: the matrix instruction's MX block b of a row is bytes 16 b ..
         # 16 b + 15 of both lane halves (tools/micro/mfma_f8_scale_probe2.hip), and lane half hh reads bytes 32 hh .. 32 hh + 31
+        # rows tokens .. np - 1 of every (slice, head): zero bytes and zero scale bytes (the GEMM used to leave them as found)
+        assert (wsc[o8:o8 + per].view(batch, heads, np_, 64)[:, :, tokens:] == 0).all(), 'padded q / k rows'
+        assert (wsc[osc:osc + batch * heads * np_ * 2].view(batch, heads, np_, 2)[:, :, tokens:] == 0).all(), 'padded scale rows'
         q8 = wsc[o8:o8 + per].view(torch.float8_e4m3fn).to(torch.float64).view(batch, heads, np_, 2, 2, 16)[:, :, :tokens]
         q8 = q8.permute(0, 1, 2, 4, 3, 5).reshape(batch, heads, tokens, 2, 32)            # (lane half, block, 16) -> (block, 32)
         sc = wsc[osc:osc + batch * heads * np_ * 2].view(batch, heads, np_, 2)[:, :, :tokens].to(torch.float64)

@@ -269,3 +269,93 @@ def test_window_goldens_cover_the_fullsize_tests():
         a = z[helpers.window_key(arch, seed, axis, w)]
         assert a.dtype == np.float16 and a.shape == ({'vits8': 384, 'vitb8': 768}[arch], n, n)
         assert np.isfinite(a).all() and float(a.astype(np.float32).std()) > 1e-3
+
+
+def _asm_functions(path):
+    """{mangled name: [instruction lines]} of a device assembly file (labels, comments and directives dropped)."""
+    import re
+    fns, cur = {}, None
+    for line in open(path):
+        m = re.match(r'^(_Z\w+):', line)
+        if m:
+            cur = fns.setdefault(m.group(1), [])
+            continue
+        if line.startswith('.Lfunc_end'):
+            cur = None
+            continue
+        t = line.strip()
+        if cur is not None and t and not t.startswith((';', '.')) and not re.match(r'^[\w.$]+:', t):
+            cur.append(t.split(';')[0].strip())
+    return fns
+
+
+def _vregs(tok):
+    """VGPR numbers named by an operand token ('v12', 'v[4:7]'); empty for anything else."""
+    import re
+    m = re.fullmatch(r'v(\d+)', tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r'v\[(\d+):(\d+)\]', tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def _operands(ins):
+    parts = ins.split(None, 1)
+    return [o.strip() for o in parts[1].split(',')] if len(parts) > 1 else []
+
+
+def test_hand_waited_registers_in_the_disassembly():
+    """Two places wait by hand for values the compiler believes are already there; both are properties of the
+    generated code, so they are checked on it:
+      * sim_mfma_few_kernel requests its query rows with asm loads and waits for them with a counted vmcnt behind two parts'
+        LDS-DMA pieces: nothing may touch the loaded registers between the loads and that wait;
+      * attn_fp8_kernel<*, true> masks its per-row E8M0 scale bytes in an asm statement that carries the wait states
+        v_mfma_scale needs behind a VALU write of its scale operand: every per-lane scale register an MFMA reads must have been
+        written last by such a statement (not by a copy or a reload the compiler put in front of the MFMA)."""
+    import re
+    import shutil
+    if not shutil.which('/opt/rocm/bin/hipcc'):
+        pytest.skip('no hipcc')
+    for src in ('sim_mfma.hip', 'attention_fp8.hip'):
+        r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'kernel_asm.sh'), src], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+    few = [v for k, v in _asm_functions('/tmp/vittf_asm/sim_mfma.s').items() if 'sim_mfma_few_kernel' in k]
+    assert len(few) == 1
+    ins = few[0]
+    loads = [i for i, t in enumerate(ins) if t.startswith('global_load_dwordx4') and ' off' in t]
+    assert len(loads) >= 6
+    first, last = loads[0], loads[5]
+    assert last - first <= 40, 'the six query-row loads are one group (address arithmetic between them)'
+    regs = set().union(*(_vregs(_operands(ins[i])[0]) for i in loads[:6]))
+    assert len(regs) == 24
+    wait = next(i for i in range(last, len(ins)) if re.match(r's_waitcnt vmcnt\(8\)', ins[i]))
+    for t in ins[last + 1:wait]:
+        touched = set().union(*(_vregs(o) for o in _operands(t)))
+        assert not (touched & regs), f'{t!r} touches a query register before the counted wait'
+    dma = [t for t in ins[last + 1:wait] if t.startswith(('global_load_lds', 'buffer_load')) or ' lds' in t]
+    assert len(dma) == 8, f'{len(dma)} LDS-DMA pieces between the query loads and vmcnt(8)'
+    fns = {k: v for k, v in _asm_functions('/tmp/vittf_asm/attention_fp8.s').items() if 'attn_fp8_kernel' in k and 'Lb1E' in k}
+    assert len(fns) == 2
+    for name, ins in fns.items():
+        n_row = 0
+        for i, t in enumerate(ins):
+            if not t.startswith('v_mfma_scale'):
+                continue
+            ops = _operands(t.split(' op_sel')[0])
+            for sreg in ops[4:6]:
+                (r_,) = _vregs(sreg)
+                j = next((j for j in range(i - 1, -1, -1) if _operands(ins[j]) and r_ in _vregs(_operands(ins[j])[0])
+                          and not ins[j].startswith(('s_', 'ds_write', 'buffer_store', 'global_store', 'scratch_store'))), None)
+                assert j is not None, (name, t)
+                w = ins[j]
+                if re.match(r'v_and_b32 v\d+, 0xff, v\d+$', w) and ins[j + 1] == 's_nop 7':
+                    n_row += 1
+                    continue
+                if re.match(r'v_mov_b32_e32 v\d+, (0x[0-9a-f]+|\d+)$', w):      # a uniform scale: the same byte in every lane
+                    continue
+                states = 0                                                      # any other writer: far enough in front of the MFMA
+                for x in ins[j + 1:i]:
+                    m = re.match(r's_nop (\d+)', x)
+                    states += int(m.group(1)) + 1 if m else 1
+                assert states >= 8, (name, w, states, t)
+        assert n_row >= 8, (name, n_row)

@@ -495,6 +495,23 @@ void vittf_fp8_ws_pointers(void* ws, int32_t batch, int32_t tokens, int32_t head
                            unsigned char** k8, unsigned char** qs, unsigned char** ks, int32_t* np);   // attention_fp8.hip
 
 // Attention.qkv with fp8 outputs for vittf_attention_fp8_rows: see include/vittf.h
+// The last 64-row tile of every (slice, head) of q8 / k8 and of their scale bytes, zeroed in front of the GEMM that fills its valid
+// rows: the rows tokens .. np - 1 are read by the attention kernel's last key / query tile (and masked behind the product); a zero
+// byte is a valid e4m3 value and a valid E8M0 scale, what an earlier call left there may be neither.
+namespace {
+__global__ __launch_bounds__(256) void fp8_zero_last_tile(unsigned char* __restrict__ q8, unsigned char* __restrict__ k8,
+                                                          unsigned char* __restrict__ qs, unsigned char* __restrict__ ks, int np) {
+  const int64_t row0 = (int64_t)blockIdx.x * np + np - 64;
+  const uint4 z = {0u, 0u, 0u, 0u};
+  reinterpret_cast<uint4*>(q8 + row0 * 64)[threadIdx.x] = z;
+  reinterpret_cast<uint4*>(k8 + row0 * 64)[threadIdx.x] = z;
+  if (threadIdx.x < 8) {
+    reinterpret_cast<uint4*>(qs + row0 * 2)[threadIdx.x] = z;
+    reinterpret_cast<uint4*>(ks + row0 * 2)[threadIdx.x] = z;
+  }
+}
+}  // namespace
+
 extern "C" int vittf_gemm_qkv_fp8(const void* a, const void* w, const float* bias, void* qkv_out, int64_t rows, int32_t n,
                                   int32_t k, int32_t tokens, int32_t heads, int32_t dtype, void* ws, size_t ws_bytes,
                                   void* stream) {
@@ -513,6 +530,8 @@ extern "C" int vittf_gemm_qkv_fp8(const void* a, const void* w, const float* bia
   if ((int64_t)batch * heads * np * 64 > 0xfffffff0ll) return VITTF_ERR_INVALID_ARG;       // 32-bit byte offsets into q8 / k8
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(f8.amax, 0, (size_t)batch * heads * 3 * 4, st) != hipSuccess) return VITTF_ERR_LAUNCH;
+  if (np != tokens)
+    hipLaunchKernelGGL(fp8_zero_last_tile, dim3((unsigned)(batch * heads)), dim3(256), 0, st, f8.q8, f8.k8, f8.qs, f8.ks, np);
   vittf_note_kernel(VITTF_KERNEL_GEMM_QKV, "gemm_pp_kernel<qkv -> fp8 q, k + row scales>");
   if (dtype == VITTF_BF16) return launch_pp<VITTF_BF16>(a, w, bias, qkv_out, rows, n, k, PP_EPI_QKV_FP8, tokens, st, f8);
   return launch_pp<VITTF_FP16>(a, w, bias, qkv_out, rows, n, k, PP_EPI_QKV_FP8, tokens, st, f8);

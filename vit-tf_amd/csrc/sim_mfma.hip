@@ -256,19 +256,23 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
   const int h = lane >> 5, l31 = lane & 31;
   const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(ring);
   const int64_t last_chunk = nvox - 8;
-  // (layout of a part, source-side swizzle and the transposing read: sim_mfma_kernel above; 4 DMA pieces per wave and part)
+  // (layout of a part, source-side swizzle and the transposing read: sim_mfma_kernel above; FEW_PIECES DMA pieces per wave and
+  //  part: the counted wait behind the query loads below is derived from the same constant)
+  constexpr int FEW_PIECES = 4;
+  static_assert(FEW_PIECES * 8 * 1024 == SM_FEW_PART, "a part = 8 waves x FEW_PIECES pieces of 1 KB");
 #define SM_STAGE_ROWS(T, P)                                                                                \
   {                                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
-      const int r_ = 2 * (wave * 4 + i) + h;                                                               \
+    _Pragma("unroll") for (int i = 0; i < FEW_PIECES; ++i) {                                                     \
+      const int r_ = 2 * (wave * FEW_PIECES + i) + h;                                                      \
       int64_t vs_ = (int64_t)(T) * SM_VOX + 8 * (l31 ^ (4 * (r_ & 3)));                                    \
       vs_ = vs_ < last_chunk ? vs_ : last_chunk;                                                           \
       lds_dma16_flat(feat + (int64_t)((P) * SM_FEW_ROWS + r_) * nvox + vs_,                                \
-                     ring_lds + ((P) % 3) * SM_FEW_PART + (wave * 4 + i) * 1024);                          \
+                     ring_lds + ((P) % 3) * SM_FEW_PART + (wave * FEW_PIECES + i) * 1024);                       \
     }                                                                                                      \
   }
   int t = blockIdx.x;
   const int stride = gridDim.x;
+  if (t >= ntiles) return;      // (never: the grid is min(ntiles, CUs); what follows relies on every workgroup having a first tile)
   // The query rows are requested AHEAD of the first volume parts, by loads hipcc does not see (round 4): its own wait for
   // them would be vmcnt(0), i.e. it would also wait for the 8 LDS-DMA pieces of parts 0 and 1 -- the memory counter retires
   // in order -- and the query images would only be built once 64 KB of volume had come in from HBM.  Issued first and waited
@@ -282,9 +286,10 @@ __global__ __launch_bounds__(SM_THREADS) void sim_mfma_few_kernel(const unsigned
     const float* src = qf + (int64_t)(p < n_q ? p : n_q - 1) * SM_F + 8 * c;
     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(qa[i]), "=&v"(qb[i]) : "v"(src) : "memory");
   }
-  if (t < ntiles) { SM_STAGE_ROWS(t, 0) SM_STAGE_ROWS(t, 1) }
-  if (t < ntiles) asm volatile("s_waitcnt vmcnt(8)" : "+v"(qa[0]), "+v"(qb[0]), "+v"(qa[1]), "+v"(qb[1]), "+v"(qa[2]), "+v"(qb[2]) :: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa[0]), "+v"(qb[0]), "+v"(qa[1]), "+v"(qb[1]), "+v"(qa[2]), "+v"(qb[2]) :: "memory");
+  SM_STAGE_ROWS(t, 0) SM_STAGE_ROWS(t, 1)
+  // (two parts' pieces are younger than the query loads; tests/test_host_cpu.py checks on the disassembly that nothing touches
+  //  the loaded registers between the loads and this wait)
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(qa[0]), "+v"(qb[0]), "+v"(qa[1]), "+v"(qb[1]), "+v"(qa[2]), "+v"(qb[2]) : "n"(2 * FEW_PIECES) : "memory");
   // the query images (sim_mfma_prep's arithmetic): 32 rows x 48 chunks of 8 features; rows >= n_q are zero
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
