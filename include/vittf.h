@@ -318,6 +318,17 @@ int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, in
                      const int32_t* class_start_host, int32_t classes, int32_t big_a_mean, const float* voxel_norm,
                      int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws, size_t ws_bytes, void* stream);
 
+/* The interactive query in ONE call (predict_ntf.py:56-72, 95-100): samples the annotations' features (trilinear, as
+ * vittf_sample_features) at rel_host -- fp32 [A][3] relative coordinates in HOST memory, formed as predict_ntf.py:56 does; they
+ * travel as a kernel argument, so A = class_start_host[classes] is at most VITTF_QUERY_MAX_A --, accumulates the class maps and
+ * quantises + resizes them: the same bytes as vittf_sample_features + vittf_similarity, with three launches and no copy or
+ * memset between the call and the first kernel.  ws: vittf_similarity_query_workspace_bytes(classes, nvox, A, f) bytes. */
+#define VITTF_QUERY_MAX_A 64
+size_t vittf_similarity_query_workspace_bytes(int32_t classes, int64_t nvox, int32_t annotations, int32_t f);
+int vittf_similarity_query(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* rel_host,
+                           const int32_t* class_start_host, int32_t classes, int32_t big_a_mean, const float* voxel_norm,
+                           int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws, size_t ws_bytes, void* stream);
+
 /* fp32 per-group maps without quantisation or resizing: maps_out fp32 [classes][n0*n1*n2].
  *   mode 0: predict_ntf.py:65-72 (the input of the bilateral-solver branch :73-96); mode 1: its A > 1024 variant (:62-63);
  *   mode 2: the second similarity of resample_topk (infer.py:104-106): clamp(dot, 0, 1) ** exponent, mean over each group

@@ -829,6 +829,65 @@ def test_quantize_16_per_thread_matches_bytewise_kernel(gpu, monkeypatch, grid, 
         assert float((fast[k] != ref[k]).float().mean()) <= 0.01
 
 
+@pytest.mark.parametrize('grid,vol_shape,counts', [((64, 64, 64), (512, 512, 512), (16,)),      # the bench's query: matrix cores, x 4 resize
+                                                   ((16, 16, 16), (64, 64, 64), (3, 2)),            # VALU kernel, x 2
+                                                   ((16, 16, 16), (32, 32, 32), (9,)),              # x 1
+                                                   ((8, 8, 8), (16, 16, 256), (5, 40)),             # x 16 along the last dim
+                                                   ((6, 7, 5), (60, 70, 64), (4, 1))])              # ratios 5, 5, 6.4: the general form
+def test_similarity_query_one_call_same_bytes(gpu, monkeypatch, grid, vol_shape, counts):
+    """vittf_similarity_query (what compute_similarities runs for up to 64 annotations: coordinates as a kernel argument, the
+    maxima zeroed by the sampling kernel, the power-of-two form of the quantise kernel) against the three separate steps it
+    replaces -- coordinates copied to the device, vittf_sample_features, vittf_similarity -- with the general 16-value quantise
+    kernel and with the bytewise one: the same bytes, from a workspace that starts as 0xff."""
+    lib = _lib.load()
+    g = gen(sum(grid) + sum(counts))
+    f = 384
+    feat = torch.nn.functional.normalize(torch.randn(f, *grid, generator=g), dim=0)
+    feat = torch.nn.functional.normalize((feat + 0.7 * feat[:, 2:3, 3:4, 4:5]).half().float(), dim=0).half().to(gpu)
+    ann = {f'c{i}': torch.stack([torch.randint(0, s, (n,), generator=g) for s in vol_shape], 1) for i, n in enumerate(counts)}
+    got = vt.compute_similarities(_ShapeOnly(vol_shape), feat, ann,
+                                  keep_on_device=True)
+    # the separate steps, through the C ABI
+    coords = torch.cat([ann[k] for k in ann])
+    rel = ((coords.float() + 0.5) / torch.tensor([list(vol_shape)], dtype=torch.float32) * 2.0 - 1.0).to(gpu).contiguous()
+    a = rel.shape[0]
+    qf = torch.empty(a, f, device=gpu)
+    n0, n1, n2 = grid
+    _lib.check(lib.vittf_sample_features(_lib.ptr(feat), 1, f, n0, n1, n2, _lib.ptr(rel), a, _lib.SAMPLE_MODES['bilinear'], None,
+                                         _lib.ptr(qf), _lib.stream_ptr()))
+    starts = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+    o = tuple(s // 2 for s in vol_shape)
+    for q16 in ('2', '0'):
+        monkeypatch.setenv('VITTF_SIM_QUANT16', q16)
+        ws = torch.full((lib.vittf_similarity_workspace_bytes(len(counts), n0 * n1 * n2, a),), 0xff, dtype=torch.uint8, device=gpu)
+        out = torch.empty((len(counts), *o), dtype=torch.uint8, device=gpu)
+        _lib.check(lib.vittf_similarity(_lib.ptr(feat), f, n0, n1, n2, _lib.ptr(qf), starts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        len(counts), 0, None, o[0], o[1], o[2], _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                        _lib.stream_ptr()))
+        for i, k in enumerate(ann):
+            assert int(out[i].max()) > 0
+            assert torch.equal(got[k], out[i]), (k, q16)
+    monkeypatch.setenv('VITTF_SIM_QUANT16', '1')
+    # the entry itself from a poisoned workspace; more than VITTF_QUERY_MAX_A annotations are refused
+    ws = torch.full((lib.vittf_similarity_query_workspace_bytes(len(counts), n0 * n1 * n2, a, f),), 0xff, dtype=torch.uint8, device=gpu)
+    out2 = torch.empty((len(counts), *o), dtype=torch.uint8, device=gpu)
+    rel_h = np.ascontiguousarray(rel.cpu().numpy())
+    _lib.check(lib.vittf_similarity_query(_lib.ptr(feat), f, n0, n1, n2, rel_h.ctypes.data_as(C.POINTER(C.c_float)),
+                                          starts.ctypes.data_as(C.POINTER(C.c_int32)), len(counts), 0, None, o[0], o[1], o[2],
+                                          _lib.ptr(out2), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    assert torch.equal(out2, out)
+    too_many = np.array([0, _lib.QUERY_MAX_A + 1], np.int32)
+    assert lib.vittf_similarity_query(_lib.ptr(feat), f, n0, n1, n2, rel_h.ctypes.data_as(C.POINTER(C.c_float)),
+                                      too_many.ctypes.data_as(C.POINTER(C.c_int32)), 1, 0, None, o[0], o[1], o[2], _lib.ptr(out2),
+                                      _lib.ptr(ws), ws.numel(), _lib.stream_ptr()) == -1
+
+
+class _ShapeOnly:
+    """compute_similarities only reads volume.shape unless the bilateral solver is asked for."""
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
 @pytest.mark.parametrize('grid,counts,min_a', [((7, 9, 11), (70, 3, 33), None),            # 693 voxels: rows not 16-byte aligned -> strided loads
                                                 ((16, 16, 16), (2,) * 40, None),              # 40 classes: tables through device memory
                                                 ((32, 32, 32), (16,), 8), ((24, 20, 18), (5, 1, 9), 8),   # few queries on the matrix cores

@@ -87,6 +87,9 @@ SIGNATURES = {
     'vittf_similarity_workspace_bytes': (_sz, [_i32, _i64, _i32]),
     'vittf_similarity': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _P(_i32), _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp,
                                    _sz, _vp]),
+    'vittf_similarity_query_workspace_bytes': (_sz, [_i32, _i64, _i32, _i32]),
+    'vittf_similarity_query': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _P(C.c_float), _P(_i32), _i32, _i32, _vp, _i32, _i32, _i32,
+                                         _vp, _vp, _sz, _vp]),
     'vittf_similarity_maps_f32': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _P(_i32), _i32, _i32, C.c_float, _vp, _vp,
                                             _vp, _sz, _vp]),
     'vittf_topk_voxels': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp]),
@@ -130,6 +133,7 @@ def load():
 KERNEL_CLASSES = ('patch_embed', 'layernorm', 'gemm', 'attention', 'mlp', 'gemm_qkv', 'gemm_proj', 'gemm_fc1', 'gemm_fc2',
                   'similarity')
 ABI_VERSION = 6
+QUERY_MAX_A = 64          # VITTF_QUERY_MAX_A: annotations of a vittf_similarity_query call
 
 
 def profiler_enable(on=True, classes=None):

@@ -69,6 +69,46 @@ __global__ __launch_bounds__(256) void sample_kernel(const void* __restrict__ fe
   out[e] = res;
 }
 
+// The interactive query's form (vittf_similarity_query): the relative coordinates arrive as a kernel argument (at most
+// VITTF_QUERY_MAX_A annotations: no host -> device copy in front of the query), the arithmetic is sample_kernel's trilinear
+// branch word for word, and the first threads zero the per-class maxima the accumulation kernels behind it add to (no memset).
+struct RelArg { float v[3 * VITTF_QUERY_MAX_A]; };
+__global__ __launch_bounds__(256) void sample_query_kernel(const unsigned short* __restrict__ feat, int f, int n0, int n1, int n2,
+                                                           RelArg rel, int na, const float* __restrict__ vnorm,
+                                                           float* __restrict__ out, unsigned* __restrict__ maxbits, int classes) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < classes) maxbits[e] = 0u;
+  if (e >= (int64_t)na * f) return;
+  const int a = (int)(e / f), ff = (int)(e - (int64_t)a * f);
+  const float r0 = rel.v[3 * a + 0], r1 = rel.v[3 * a + 1], r2 = rel.v[3 * a + 2];
+  const float iz = ((r0 + 1.f) * (float)n0 - 1.f) / 2.f;
+  const float iy = ((r1 + 1.f) * (float)n1 - 1.f) / 2.f;
+  const float ix = ((r2 + 1.f) * (float)n2 - 1.f) / 2.f;
+  const int64_t plane = (int64_t)n1 * n2;
+  const int64_t fbase = (int64_t)ff * n0 * plane;
+  float res = 0.f;
+  const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz;
+  const float wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy, wz0 = (fz + 1.f) - iz;
+#pragma unroll
+  for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+      for (int cx = 0; cx < 2; ++cx) {
+        const int x = x0 + cx, y = y0 + cy, z = z0 + cz;
+        const float wgt = (cx ? wx1 : wx0) * (cy ? wy1 : wy0) * (cz ? wz1 : wz0);
+        if (x >= 0 && x < n2 && y >= 0 && y < n1 && z >= 0 && z < n0) {
+          const int64_t vox = z * plane + (int64_t)y * n2 + x;
+          float val = feat_at<true>(feat, fbase + vox);
+          if (vnorm) val = val / vnorm[vox];
+          res = __fadd_rn(res, __fmul_rn(val, wgt));
+        }
+      }
+  out[e] = res;
+}
+
 // ---------------------------------------------------------------- per-voxel L2 norm (cosine similarity)
 // max(|feat[:, v]|_2, 1e-12): the denominator of F.normalize(feat, dim=0) (compare_feat_sampling.py:45,
 // tests/test_vishum.py:12).  Keeping the norms (1 MB) instead of a normalised fp32 copy of the volume (403 MB)
@@ -399,6 +439,49 @@ __global__ __launch_bounds__(256) void sim_quantize16(const float* __restrict__ 
   }
 }
 
+// The same bytes when the output's last dim is a power-of-two multiple (R2 = 1 << SH <= 16) of the map's -- the nearest resize to
+// vol.shape // 2 of a 512^3 volume's 64^3 maps: R2 = 4 -- : floorf(z * (1 / R2)) = z >> SH exactly, so a thread's 16 outputs
+// are 16 / R2 consecutive map values (one 16-, 8- or 4-byte load) each repeated R2 times, and the row split needs no division
+// per value (the general form above: 20 us for one 256^3 map, more than half of the accumulation over the 201 MB volume).
+template <int SH>
+__global__ __launch_bounds__(256) void sim_quantize16_pow2(const float* __restrict__ sim, const unsigned* __restrict__ maxbits,
+                                                           int classes, int n0, int n1, int n2, int o0, int o1, int o2,
+                                                           unsigned char* __restrict__ out) {
+  constexpr int R2 = 1 << SH, NS = 16 / R2;               // outputs per map value, map values per thread
+  const int zc = o2 >> 4;
+  const int rows = classes * o0 * o1;
+  const float s0 = (float)n0 / (float)o0, s1 = (float)n1 / (float)o1;
+  for (int64_t e64 = (int64_t)blockIdx.x * 256 + threadIdx.x; e64 < (int64_t)rows * zc; e64 += (int64_t)gridDim.x * 256) {
+    const int e = (int)e64;
+    const int row = e / zc, zi = e - row * zc;
+    const int c = row / (o0 * o1), r2 = row - c * (o0 * o1);
+    const int x = r2 / o1, y = r2 - x * o1;
+    int sx = (int)floorf((float)x * s0), sy = (int)floorf((float)y * s1);
+    sx = sx < n0 - 1 ? sx : n0 - 1; sy = sy < n1 - 1 ? sy : n1 - 1;
+    const float* src = sim + (int64_t)c * n0 * n1 * n2 + ((int64_t)sx * n1 + sy) * n2 + zi * NS;
+    const float scale = 255.0f / (0.99f * __uint_as_float(maxbits[c]));
+    float v[NS];
+    if constexpr (NS == 4) { const float4 t = *reinterpret_cast<const float4*>(src); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else if constexpr (NS == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[0] = t.x; v[1] = t.y; }
+    else {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) v[i] = src[i];
+    }
+    unsigned char b[16];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const float q = scale * v[i];
+      const int qi = (q == q) ? (int)q : 0;
+#pragma unroll
+      for (int j = 0; j < R2; ++j) b[i * R2 + j] = (unsigned char)(qi & 255);
+    }
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = (unsigned)b[4 * k] | ((unsigned)b[4 * k + 1] << 8) | ((unsigned)b[4 * k + 2] << 16) | ((unsigned)b[4 * k + 3] << 24);
+    *reinterpret_cast<uint4*>(out + (int64_t)row * o2 + 16 * zi) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 struct LabelArgs { int classes; int thr[16]; };
 
 __global__ __launch_bounds__(256) void labels_kernel(const unsigned char* __restrict__ sims, int64_t n, LabelArgs a,
@@ -479,13 +562,13 @@ namespace {
 int accumulate_class_maps(const void* feat, bool half, int32_t f, int64_t nvox, const float* qf,
                           const int32_t* class_start_host, int32_t classes, int32_t mode, float expo,
                           const float* voxel_norm, float* sim, unsigned* maxbits, float* qf_t, void* mfma_ws,
-                          size_t mfma_ws_bytes, hipStream_t st) {
+                          size_t mfma_ws_bytes, hipStream_t st, bool maxbits_zeroed = false) {
   if (mode < 0 || mode > 2 || (!half && mode != 2)) return VITTF_ERR_INVALID_ARG;
   if (class_start_host[0] != 0) return VITTF_ERR_INVALID_ARG;
   for (int c = 0; c < classes; ++c)
     if (class_start_host[c + 1] <= class_start_host[c]) return VITTF_ERR_INVALID_ARG;  // empty class: caller drops it
   if (((uintptr_t)feat & 3) != 0) return VITTF_ERR_INVALID_ARG;
-  if (hipMemsetAsync(maxbits, 0, (size_t)classes * 4, st) != hipSuccess) return VITTF_ERR_LAUNCH;
+  if (!maxbits_zeroed && hipMemsetAsync(maxbits, 0, (size_t)classes * 4, st) != hipSuccess) return VITTF_ERR_LAUNCH;
 
   const int total_a = class_start_host[classes];
   if (mode == 0 && half && mfma_ws_bytes) {   // many annotations, F = 384 / 768: the volume is read once (sim_mfma.hip)
@@ -551,6 +634,39 @@ int accumulate_class_maps(const void* feat, bool half, int32_t f, int64_t nvox, 
 }
 }  // namespace
 
+namespace {
+// the quantise + resize launch behind the accumulation (predict_ntf.py:95-100)
+int quantize_maps(const float* sim, const unsigned* maxbits, int32_t classes, int32_t n0, int32_t n1, int32_t n2, int32_t o0,
+                  int32_t o1, int32_t o2, uint8_t* out, hipStream_t st) {
+  const int64_t total_out = (int64_t)classes * o0 * o1 * o2;
+  int64_t qblocks = (total_out + 255) / 256;
+  if (qblocks > 8192) qblocks = 8192;
+  const char* q16_env = getenv("VITTF_SIM_QUANT16");   // (read per call: the tests compare the kernels; 2 = the general 16-value form)
+  const int q16 = q16_env ? atoi(q16_env) : 1;
+  if (q16 != 0 && o2 % 16 == 0 && ((uintptr_t)out & 15) == 0 && total_out / 16 < 0x7fffffff && (int64_t)classes * o0 * o1 < 0x7fffffff) {
+    qblocks = (total_out / 16 + 255) / 256;
+    if (qblocks > 16384) qblocks = 16384;
+    const int r2 = o2 % n2 == 0 ? o2 / n2 : 0;
+    const bool pow2 = q16 == 1 && (r2 == 1 || r2 == 2 || r2 == 4 || r2 == 8 || r2 == 16) && ((uintptr_t)sim & 15) == 0 && n2 % (16 / r2) == 0 &&
+                      ((int64_t)n2 * 4) % 16 == 0;
+#define SIM_Q16P(SH) hipLaunchKernelGGL((sim_quantize16_pow2<SH>), dim3((unsigned)qblocks), dim3(256), 0, st, sim, maxbits, classes, n0, n1, n2, o0, o1, o2, out)
+    if (pow2 && r2 == 1) SIM_Q16P(0);
+    else if (pow2 && r2 == 2) SIM_Q16P(1);
+    else if (pow2 && r2 == 4) SIM_Q16P(2);
+    else if (pow2 && r2 == 8) SIM_Q16P(3);
+    else if (pow2 && r2 == 16) SIM_Q16P(4);
+    else
+      hipLaunchKernelGGL(sim_quantize16, dim3((unsigned)qblocks), dim3(256), 0, st, sim, maxbits, classes, n0, n1, n2, o0, o1,
+                         o2, out);
+#undef SIM_Q16P
+  } else {
+    hipLaunchKernelGGL(sim_quantize, dim3((unsigned)qblocks), dim3(256), 0, st, sim, maxbits, classes, n0, n1, n2, o0, o1,
+                       o2, out);
+  }
+  return vittf_check_launch();
+}
+}  // namespace
+
 extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* qf,
                                 const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
                                 const float* voxel_norm, int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws,
@@ -570,20 +686,40 @@ extern "C" int vittf_similarity(const uint16_t* feat, int32_t f, int32_t n0, int
   const int rc = accumulate_class_maps(feat, true, f, nvox, qf, class_start_host, classes, big_a_mean ? 1 : 0, 0.f,
                                        voxel_norm, sim, maxbits, qf_t, wsb + L.mfma, L.mfma_bytes, st);
   if (rc != VITTF_OK) return rc;
-  const int64_t total_out = (int64_t)classes * o0 * o1 * o2;
-  int64_t qblocks = (total_out + 255) / 256;
-  if (qblocks > 8192) qblocks = 8192;
-  const char* q16_env = getenv("VITTF_SIM_QUANT16");   // (read per call: the tests compare the two kernels)
-  if ((!q16_env || atoi(q16_env) != 0) && o2 % 16 == 0 && ((uintptr_t)out & 15) == 0 && total_out / 16 < 0x7fffffff && (int64_t)classes * o0 * o1 < 0x7fffffff) {
-    qblocks = (total_out / 16 + 255) / 256;
-    if (qblocks > 16384) qblocks = 16384;
-    hipLaunchKernelGGL(sim_quantize16, dim3((unsigned)qblocks), dim3(256), 0, st, sim, maxbits, classes, n0, n1, n2, o0, o1,
-                       o2, out);
-  } else {
-    hipLaunchKernelGGL(sim_quantize, dim3((unsigned)qblocks), dim3(256), 0, st, sim, maxbits, classes, n0, n1, n2, o0, o1,
-                       o2, out);
-  }
-  return vittf_check_launch();
+  return quantize_maps(sim, maxbits, classes, n0, n1, n2, o0, o1, o2, out, st);
+}
+
+extern "C" size_t vittf_similarity_query_workspace_bytes(int32_t classes, int64_t nvox, int32_t annotations, int32_t f) {
+  if (classes <= 0 || nvox < 0 || annotations <= 0 || f <= 0) return 0;
+  return sim_ws_layout(classes, nvox, annotations).total + align256((size_t)annotations * f * 4);
+}
+
+extern "C" int vittf_similarity_query(const uint16_t* feat, int32_t f, int32_t n0, int32_t n1, int32_t n2, const float* rel_host,
+                                      const int32_t* class_start_host, int32_t classes, int32_t big_a_mean,
+                                      const float* voxel_norm, int32_t o0, int32_t o1, int32_t o2, uint8_t* out, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  if (!feat || !rel_host || !class_start_host || !out || !ws) return VITTF_ERR_INVALID_ARG;
+  if (f <= 0 || f > 4096 || n0 <= 0 || n1 <= 0 || n2 <= 0 || classes <= 0 || o0 <= 0 || o1 <= 0 || o2 <= 0)
+    return VITTF_ERR_INVALID_ARG;
+  const int a = class_start_host[classes];
+  if (a <= 0 || a > VITTF_QUERY_MAX_A || classes > 256) return VITTF_ERR_INVALID_ARG;
+  const int64_t nvox = (int64_t)n0 * n1 * n2;
+  const SimWs L = sim_ws_layout(classes, nvox, a);
+  if (ws_bytes < L.total + align256((size_t)a * f * 4)) return VITTF_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* wsb = (char*)ws;
+  unsigned* maxbits = (unsigned*)wsb;
+  float* qf = (float*)(wsb + L.total);
+  RelArg rel;
+  for (int i = 0; i < 3 * VITTF_QUERY_MAX_A; ++i) rel.v[i] = i < 3 * a ? rel_host[i] : 0.f;
+  const int64_t total = (int64_t)a * f;
+  hipLaunchKernelGGL(sample_query_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, feat, f, n0, n1, n2, rel, a,
+                     voxel_norm, qf, maxbits, classes);
+  const int rc = accumulate_class_maps(feat, true, f, nvox, qf, class_start_host, classes, big_a_mean ? 1 : 0, 0.f, voxel_norm,
+                                       (float*)(wsb + L.maps), maxbits, (float*)(wsb + L.qf_t), wsb + L.mfma, L.mfma_bytes, st,
+                                       /*maxbits_zeroed=*/true);
+  if (rc != VITTF_OK) return rc;
+  return quantize_maps((const float*)(wsb + L.maps), maxbits, classes, n0, n1, n2, o0, o1, o2, out, st);
 }
 
 extern "C" int vittf_similarity_maps_f32(const void* feat, int32_t feat_is_fp16, int32_t f, int32_t n0, int32_t n1,

@@ -87,25 +87,39 @@ def compute_similarities(volume, features, annotations, bilateral_solver=False, 
     sim_shape = tuple(d // 2 for d in in_dims)
 
     coords = torch.cat([torch.as_tensor(annotations[k]).reshape(-1, 3) for k in names])
-    # rel = (abs + 0.5) / extent * 2 - 1 in fp32, exactly the reference expression (predict_ntf.py:56)
-    ext = torch.tensor([list(in_dims)], dtype=torch.float32)
-    rel = ((coords.float() + 0.5) / ext * 2.0 - 1.0).to(dev).contiguous()
-    a_total = rel.shape[0]
+    a_total = coords.shape[0]
     if voxel_norm is not None:
         vnorm = torch.as_tensor(voxel_norm).to(dev, torch.float32).contiguous()
         if vnorm.numel() != n0 * n1 * n2:
             raise ValueError(f'voxel_norm has {vnorm.numel()} entries for {n0 * n1 * n2} voxels')
     else:
         vnorm = voxel_norms(feat) if normalize else None
+    counts = [int(torch.as_tensor(annotations[k]).reshape(-1, 3).shape[0]) for k in names]
+    starts = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+    big = int(len(annotations) == 1 and counts[0] > 1024)      # predict_ntf.py:62
+    nclass = len(names)
+    # rel = (abs + 0.5) / extent * 2 - 1 in fp32, exactly the reference expression (predict_ntf.py:56)
+    if not bilateral_solver and a_total <= _lib.QUERY_MAX_A and nclass <= 256:
+        # the interactive query: ONE library call -- the coordinates travel as a kernel argument (numpy float32 here: the same
+        # correctly rounded operations in the same order as the torch expression below), three launches, no copy, no memset
+        rel_h = np.ascontiguousarray(((coords.numpy().astype(np.float32) + np.float32(0.5)) / np.asarray([in_dims], np.float32)
+                                      * np.float32(2.0) - np.float32(1.0)), dtype=np.float32)
+        ws_bytes = lib.vittf_similarity_query_workspace_bytes(nclass, n0 * n1 * n2, a_total, f)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((nclass, *sim_shape), dtype=torch.uint8, device=dev)
+        _lib.check(lib.vittf_similarity_query(_lib.ptr(feat), f, n0, n1, n2, rel_h.ctypes.data_as(C.POINTER(C.c_float)),
+                                              starts.ctypes.data_as(C.POINTER(C.c_int32)), nclass, big, _lib.ptr(vnorm),
+                                              sim_shape[0], sim_shape[1], sim_shape[2], _lib.ptr(out), _lib.ptr(ws), ws_bytes,
+                                              _lib.stream_ptr()), 'vittf_similarity_query')
+        host = out if keep_on_device else _to_host(out)
+        return _with_empty_classes({k: host[i] for i, k in enumerate(names)}, annotations, sim_shape, dev, keep_on_device)
+    ext = torch.tensor([list(in_dims)], dtype=torch.float32)
+    rel = ((coords.float() + 0.5) / ext * 2.0 - 1.0).to(dev).contiguous()
     qf = torch.empty((a_total, f), dtype=torch.float32, device=dev)
     _lib.check(lib.vittf_sample_features(_lib.ptr(feat), 1, f, n0, n1, n2, _lib.ptr(rel), a_total,
                                          _lib.SAMPLE_MODES['bilinear'], _lib.ptr(vnorm), _lib.ptr(qf), _lib.stream_ptr()),
                'vittf_sample_features')
 
-    counts = [int(torch.as_tensor(annotations[k]).reshape(-1, 3).shape[0]) for k in names]
-    starts = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
-    big = int(len(annotations) == 1 and counts[0] > 1024)      # predict_ntf.py:62
-    nclass = len(names)
     ws_bytes = lib.vittf_similarity_workspace_bytes(nclass, n0 * n1 * n2, a_total)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     if bilateral_solver:
