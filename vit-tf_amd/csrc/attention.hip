@@ -35,11 +35,11 @@ constexpr int BUF_BYTES = 2 * KV_TILE_BYTES; // K | V
 
 // One 64-key tile for this wave's 32 query rows.  BUF selects the LDS buffer at compile time so that every
 // ds_read offset is an immediate on one of six per-lane base registers.  LAST masks keys >= tokens.
-template <int DT, int BUF, bool LAST, bool PRE>
+template <int DT, int BUF, bool LAST>
 __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, const char* ka2, const char* ka3,
                                           const char* va0, const char* va1, const s16x8_t& q0, const s16x8_t& q1,
                                           const s16x8_t& q2, const s16x8_t& q3, f32x16_t& o0, f32x16_t& o1,
-                                          f32x16_t& negm, float& m_run, float& l_run, int t, int tokens, int h, float c) {
+                                          float& m_run, float& l_run, int t, int tokens, int h, float c) {
   // Two 32-key halves, each carried from S^T to O^T: the score registers (16) and the P fragments (8) of one half are
   // (nearly) all that is live.  The halves are NOT fenced off from each other any more: within the register budget of
   // the launch bounds hipcc sinks the O^T MFMAs of one half into the exp2 stream of the next (an `s_nop 10` behind the
@@ -48,12 +48,8 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
   for (int kt = 0; kt < 2; ++kt) {
     constexpr int kb = BUF * BUF_BYTES;
     f32x16_t sacc;
-    if constexpr (PRE) {
-      sacc = negm;                       // C input = -M: the MFMA chain returns s' - M, no VALU subtraction
-    } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    }
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
     sacc = mfma32<DT>(*reinterpret_cast<const s16x8_t*>(ka0 + kb + 4096 * kt), q0, sacc);
     sacc = mfma32<DT>(*reinterpret_cast<const s16x8_t*>(ka1 + kb + 4096 * kt), q1, sacc);
     sacc = mfma32<DT>(*reinterpret_cast<const s16x8_t*>(ka2 + kb + 4096 * kt), q2, sacc);
@@ -67,81 +63,34 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
     }
 
     float p[16];
-    if constexpr (PRE) {
-      // ---- lazy-maximum softmax (q arrives pre-scaled by log2(e)/8, so s' is already in exp2 units) ----
-      // M is only a scale: softmax is exact for ANY M as long as nothing overflows, so the common path has no
-      // maximum, no subtraction and no rescale: p = exp2(s' - M) straight from the MFMA result.  M is fixed by
-      // the first 32 keys and raised only when a half's row sum says the values have grown too large for the
-      // 16-bit P (fp16: 2^13; bf16 shares fp32's exponent range: 2^30) -- a rare, wave-uniform slow path.
-      constexpr float THR = DT == VITTF_FP16 ? 8192.f : 1073741824.f;
-      const bool first = (t == 0) && (kt == 0);
-      float psum0 = 0.f, psum1 = 0.f;
+    // ---- online softmax (lane = one query column; 16 of the half's 32 keys are in this lane) ----
+    float tmax = max3_f32(sacc[0], sacc[1], sacc[2]);
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        p[r] = __builtin_amdgcn_exp2f(sacc[r]);
-        p[r + 1] = __builtin_amdgcn_exp2f(sacc[r + 1]);
-        psum0 += p[r];
-        psum1 += p[r + 1];
-      }
-      float ps = psum0 + psum1;
-      if (first || __any(!(ps <= THR))) {
-        float tmax = max3_f32(sacc[0], sacc[1], sacc[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) tmax = max3_f32(tmax, sacc[r], sacc[r + 1]);
-        tmax = max3_f32(tmax, sacc[15], sacc[15]);
-        const unsigned tb = __float_as_uint(tmax);
-        const auto sw = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);
-        tmax = max3_f32(tmax, __uint_as_float(sw[0]), __uint_as_float(sw[1]));      // both lane halves agree
-        const float delta = first ? tmax : max3_f32(tmax, 0.f, 0.f);               // M moves by delta
-        if (!first) {
-          const float alpha = __builtin_amdgcn_exp2f(-delta);
-          l_run *= alpha;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] -= delta;
-        psum0 = 0.f; psum1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          p[r] = __builtin_amdgcn_exp2f(sacc[r] - delta);
-          p[r + 1] = __builtin_amdgcn_exp2f(sacc[r + 1] - delta);
-          psum0 += p[r];
-          psum1 += p[r + 1];
-        }
-        ps = psum0 + psum1;
-      }
-      l_run += ps;
-    } else {
-      // ---- online softmax (lane = one query column; 16 of the half's 32 keys are in this lane) ----
-      float tmax = max3_f32(sacc[0], sacc[1], sacc[2]);
-#pragma unroll
-      for (int r = 3; r < 15; r += 2) tmax = max3_f32(tmax, sacc[r], sacc[r + 1]);
-      tmax = max3_f32(tmax, sacc[15], sacc[15]);
-      float m_new;
-      {
-        const unsigned tb = __float_as_uint(tmax);
-        const auto sw = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);   // one of the two holds the other half
-        m_new = max3_f32(m_run, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      }
-      const float mc = m_new * c;
-      if (!__all(m_new == m_run)) {   // rare after the first tiles: rescale what was accumulated at the old maximum
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        l_run *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        m_run = m_new;
-      }
-      float psum0 = 0.f, psum1 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -mc));
-        p[r + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[r + 1], c, -mc));
-        psum0 += p[r];
-        psum1 += p[r + 1];
-      }
-      l_run += psum0 + psum1;
+    for (int r = 3; r < 15; r += 2) tmax = max3_f32(tmax, sacc[r], sacc[r + 1]);
+    tmax = max3_f32(tmax, sacc[15], sacc[15]);
+    float m_new;
+    {
+      const unsigned tb = __float_as_uint(tmax);
+      const auto sw = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);   // one of the two holds the other half
+      m_new = max3_f32(m_run, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
+    const float mc = m_new * c;
+    if (!__all(m_new == m_run)) {   // rare after the first tiles: rescale what was accumulated at the old maximum
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      m_run = m_new;
+    }
+    float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -mc));
+      p[r + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[r + 1], c, -mc));
+      psum0 += p[r];
+      psum1 += p[r + 1];
+    }
+    l_run += psum0 + psum1;
     s16x8_t pf[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -170,8 +119,8 @@ __device__ __forceinline__ void attn_tile(const char* ka0, const char* ka1, cons
   }
 }
 
-template <int DT, bool PRE>
-__global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned short* __restrict__ qkv,
+template <int DT>
+__global__ __launch_bounds__(256, 4) void attn_kernel(const unsigned short* __restrict__ qkv,
                                                       unsigned short* __restrict__ out, int tokens, int heads,
                                                       int q_tiles, int total, float c) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];  // [buffer][K | V]
@@ -260,9 +209,9 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned s
   const char* const va0 = smem + vl0;          // jj = 0
   const char* const va1 = smem + (vl0 ^ 32);   // jj = 1: (key >> 2) & 3 gains 2 -> chunk index ^ 2
 
-  f32x16_t o0, o1, negm;
+  f32x16_t o0, o1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; negm[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
   ATTN_STAGE_TILE(0, 0)
@@ -289,7 +238,7 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned s
 #define ATTN_STEP(BUFC, BUFN)                                                                                          \
   {                                                                                                                    \
     ATTN_STAGE_TILE(t + 1, BUFN)                                                                                       \
-    attn_tile<DT, BUFC, false, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c); \
+    attn_tile<DT, BUFC, false>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c); \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* this wave's DMA pieces have landed ... */                    \
     __syncthreads();                                    /* ... and everybody's have, and everybody is done reading */  \
     ++t;                                                                                                               \
@@ -300,8 +249,8 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void attn_kernel(const unsigned s
   }
   if (t + 1 < nt) ATTN_STEP(0, 1)
 #undef ATTN_STEP
-  if (t & 1) attn_tile<DT, 1, true, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c);
-  else       attn_tile<DT, 0, true, PRE>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, negm, m_run, l_run, t, tokens, h, c);
+  if (t & 1) attn_tile<DT, 1, true>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
+  else       attn_tile<DT, 0, true>(ka0, ka1, ka2, ka3, va0, va1, q0, q1, q2, q3, o0, o1, m_run, l_run, t, tokens, h, c);
 
   // ---- normalise and store: lane owns query row `qrow`, columns 32 dvt + 8 g + 4 h + {0..3} ----
   float l_tot;
@@ -351,7 +300,7 @@ extern "C" int vittf_attention(const void* qkv, void* out, int32_t batch, int32_
   }
   // q as the model produces it: the online-maximum kernel of this file
 #define VITTF_ATTN_LAUNCH(DTV)                                                                              \
-  hipLaunchKernelGGL((attn_kernel<DTV, false>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,  \
+  hipLaunchKernelGGL((attn_kernel<DTV>), dim3(total), dim3(256), 0, st, (const unsigned short*)qkv,  \
                      (unsigned short*)out, tokens, heads, q_tiles, total, c)
   vittf_note_kernel(VITTF_KERNEL_ATTENTION, "attn_kernel<online maximum>");
   if (dtype == VITTF_BF16) VITTF_ATTN_LAUNCH(VITTF_BF16);
