@@ -208,19 +208,20 @@ def test_bench_pmc_traffic_only_for_the_measured_kernel(tmp_path, monkeypatch):
 
 
 def test_engine_batch_follows_a_workspace_budget(monkeypatch):
-    """Slices per engine call: 256 at the metric's shape, scaled down with the token count so that a call's row count stays
-    where 256 x 4097 puts it; an explicit request or VITTF_ENGINE_BATCH wins."""
+    """Slices per engine call: 512 at the metric's shape (256 for models wider than 384), scaled down with the token count so
+    that a call's row count stays where 512 x 4097 puts it; an explicit request or VITTF_ENGINE_BATCH wins."""
     from vit_tf_amd.extract import engine_batch_for
     monkeypatch.delenv('VITTF_ENGINE_BATCH', raising=False)
-    assert engine_batch_for(4097, 384) == 256
-    assert engine_batch_for(16385, 384) == 64          # sub/infer_and_merge.sh: fos 128, 1024 x 1024 slices
-    assert engine_batch_for(4097, 768) == 256          # ViT-B/8: the same rows per call (11 GB of workspace)
+    assert engine_batch_for(4097, 384) == 512
+    assert engine_batch_for(16385, 384) == 128         # sub/infer_and_merge.sh: fos 128, 1024 x 1024 slices
+    assert engine_batch_for(4097, 768) == 256          # ViT-B/8: half the slices, the same 11 GB of workspace
     assert engine_batch_for(16385, 768) == 64
-    assert engine_batch_for(65, 384) == 256 and engine_batch_for(10 ** 9, 384) == 1
+    assert engine_batch_for(65, 384) == 512 and engine_batch_for(10 ** 9, 384) == 1
     assert engine_batch_for(4097, 384, 32) == 32
     from vit_tf_amd.extract import AtLeast             # the reference's --batch-size: a lower bound, never a smaller launch
-    assert engine_batch_for(4097, 384, AtLeast(4)) == 256 and engine_batch_for(4097, 384, AtLeast(300)) == 300
-    assert engine_batch_for(16385, 384, AtLeast(2)) == 64
+    assert engine_batch_for(4097, 384, AtLeast(4)) == 512 and engine_batch_for(4097, 384, AtLeast(600)) == 600
+    assert engine_batch_for(4097, 768, AtLeast(300)) == 300 and engine_batch_for(4097, 768, AtLeast(5000)) == 1024
+    assert engine_batch_for(16385, 384, AtLeast(2)) == 128
     monkeypatch.setenv('VITTF_ENGINE_BATCH', '8')
     assert engine_batch_for(4097, 384, 32) == 8
 

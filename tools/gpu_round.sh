@@ -33,20 +33,20 @@ for s in "$@"; do
     pmcattn)  step pmc_attn 900 bash tools/pmc_attn.sh attn ;;
     pmcsim)   step pmc_sim 600 bash tools/pmc_sim.sh ;;
     pmcjson)  # the records bench.py reads for roofline.traffic: attention at the engine's batch (256 slices), the 16-query similarity
-              export BATCH=256 DT=fp16
+              export BATCH=512 DT=fp16
               step pmc_attn256 900 bash tools/pmc_attn.sh attn
               unset BATCH
-              python tools/pmc_json.py attention $OUT/pmc_attn256.log attn_pp64 $OUT/pmc_attention.json batch=256 tokens=4097 heads=6 "kernel=attn_pp64_kernel<fp16>" > /dev/null
+              python tools/pmc_json.py attention $OUT/pmc_attn256.log attn_pp64 $OUT/pmc_attention.json batch=512 tokens=4097 heads=6 "kernel=attn_pp64_kernel<fp16>" > /dev/null
               step pmc_sim 600 bash tools/pmc_sim.sh
               python tools/pmc_json.py similarity $OUT/pmc_sim.log sim_mfma_few $OUT/pmc_similarity.json batch=16 nvox=262144 features=384 kernel=sim_mfma_few_kernel > /dev/null ;;
-    pmctail)  export BATCH=256 DT=fp16
+    pmctail)  export BATCH=512 DT=fp16
               step pmc_tail 900 bash tools/pmc_attn.sh tail
               unset BATCH
-              python tools/pmc_json.py block_tail $OUT/pmc_tail.log tail_fx_kernel $OUT/pmc_block_tail.json batch=256 tokens=4097 features=384 > /dev/null ;;
-    pmcqkv)   export BATCH=256 DT=fp16
+              python tools/pmc_json.py block_tail $OUT/pmc_tail.log tail_fx_kernel $OUT/pmc_block_tail.json batch=512 tokens=4097 features=384 > /dev/null ;;
+    pmcqkv)   export BATCH=512 DT=fp16
               step pmc_qkv 900 bash tools/pmc_attn.sh qkv
               unset BATCH
-              python tools/pmc_json.py gemm_qkv $OUT/pmc_qkv.log gemm_as_kernel $OUT/pmc_gemm_qkv.json batch=256 tokens=4097 features=384 > /dev/null ;;
+              python tools/pmc_json.py gemm_qkv $OUT/pmc_qkv.log gemm_as_kernel $OUT/pmc_gemm_qkv.json batch=512 tokens=4097 features=384 > /dev/null ;;
     fp8)      step test_fp8 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -q -m gpu -s -p no:cacheprovider -k "fp8 or vitb8" ;;
     benchb)   for a in 16bit fp8; do step benchb_$a 600 python bench.py --arch vitb8 --workload 64 --attention $a --cpu-slices 0 --steps 2; done ;;
     benchb512) for a in 16bit fp8; do step benchb512_$a 600 python bench.py --arch vitb8 --attention $a --cpu-slices 0 --steps 2; done ;;
@@ -54,7 +54,7 @@ for s in "$@"; do
     simtests) step test_sim 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider -k "similarity or sim or golden or labels or cosine or topk" ;;
     prof8)    cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               SETTLE_S=0.05 step prof8 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof8 -- python tools/bench_kernels.py attn8 ;;
-    benchbatch) for eb in 64 128 256 512; do step benchbatch_$eb 600 python bench.py --engine-batch $eb --cpu-slices 0 --steps 2; done ;;
+    benchbatch) for eb in ${BENCH_BATCHES:-64 128 256 512}; do step benchbatch_$eb 600 python bench.py --engine-batch $eb --cpu-slices 0 --steps 2; done ;;
     bench512) step bench512 900 python bench.py ;;
     prof512)  cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
               export VITTF_BENCH_EXTRAS=0

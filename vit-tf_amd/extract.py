@@ -19,10 +19,15 @@ from . import _lib
 # axis -> (sliced volume dim, (volume dim of image rows, volume dim of image cols))      infer.py:138-147
 AXIS_DIMS = {'z': (2, (0, 1)), 'y': (1, (0, 2)), 'x': (0, (1, 2))}
 # Slices per vittf_vit_k_features call.  Slices are independent and results do not depend on the batching (tested: 31 / 32 /
-# 256 give the same bits); larger batches amortise every launch's partial last round of workgroups (the 32 CLS rows of a
-# 32-slice batch cost the whole-row GEMMs a third round): 512^3 workload 1828 / 1852 / 1870 / 1879 / 1902 / 1906 slices/s at
-# batch 32 / 31 / 64 / 128 / 256 / 512 on one box.  256 slices of N = 4097 tokens at D = 384 = 5.6 GB of workspace (of 288 GB).
-DEFAULT_ENGINE_BATCH = 256
+# 256 / 512 give the same bits); larger batches amortise every launch's partial last round of workgroups.  The persistent
+# kernels of the ViT-S path hand out 128- / 256-row tiles to 256 CUs: 256 slices x 4097 tokens are 16.004 rounds of the qkv
+# projection's tiles and 32.01 of the block tail's -- a seventeenth / thirty-third round for one tile in 256 --, 512 slices
+# halve that waste: 2318 -> 2340 slices/s on one box (block tail 3.07 -> 2.96 ms per 256 slices, qkv 0.989 -> 0.976; round 5).
+# 512 slices of N = 4097 tokens at D = 384 = 11 GB of workspace (of 288 GB).  D = 768 stays at 256: its widest buffer (rows x
+# 4 D 16-bit values) must stay below 2^32 elements.
+DEFAULT_ENGINE_BATCH = 512
+DEFAULT_ENGINE_BATCH_WIDE = 256       # embed_dim > 384
+MAX_ENGINE_BATCH_ROWS = 1024 * 4097   # what an AtLeast request may raise a call to (32-bit offsets into the widest buffers)
 
 
 class AtLeast(int):
@@ -33,20 +38,20 @@ class AtLeast(int):
 
 
 def engine_batch_for(tokens, embed_dim, requested=None):
-    """Slices per engine call.  The default keeps the ROW count of a call at what 256 slices of N = 4097 are (1.05 M rows:
-    5.6 GB of workspace per stream lane at D = 384, 11 GB at D = 768; the widest buffer, rows x 4 D 16-bit values, stays
-    below 2^32 elements), whatever the token count: 256 * 4097 / tokens, clamped to 1 .. 256 -- the fos-128 preset
-    (N = 16385) then runs 64 slices per call.  `requested`: a plain int (bench.py --engine-batch, tests) is taken
-    literally, an `AtLeast` (infer.py --batch-size, compute_qkv's batch_size) only raises the default; VITTF_ENGINE_BATCH
-    overrides both; results never depend on any of them."""
+    """Slices per engine call.  The default keeps the ROW count of a call at what 512 slices of N = 4097 are for D <= 384
+    (2.1 M rows: 11 GB of workspace) and 256 slices for wider models (1.05 M rows: 11 GB at D = 768; the widest buffer, rows x
+    4 D 16-bit values, stays below 2^32 elements), whatever the token count: base * 4097 / tokens, clamped to 1 .. base -- the
+    fos-128 preset (N = 16385) then runs 128 slices per call.  `requested`: a plain int (bench.py --engine-batch, tests) is
+    taken literally, an `AtLeast` (infer.py --batch-size, compute_qkv's batch_size) only raises the default;
+    VITTF_ENGINE_BATCH overrides both; results never depend on any of them."""
     env = __import__('os').environ.get('VITTF_ENGINE_BATCH')
     if env:
         return max(1, int(env))
-    default = max(1, min(DEFAULT_ENGINE_BATCH, DEFAULT_ENGINE_BATCH * 4097 // int(tokens)))
+    base = DEFAULT_ENGINE_BATCH if int(embed_dim) <= 384 else DEFAULT_ENGINE_BATCH_WIDE
+    default = max(1, min(base, base * 4097 // int(tokens)))
     if isinstance(requested, AtLeast):
-        # (never above 4 x the default: the widest buffers of a call -- rows x 4 D 16-bit values, the fp8 operand rows -- are
-        #  addressed with 32-bit offsets)
-        return min(max(int(requested), default), 4 * default)
+        # (capped: the widest buffers of a call -- rows x 4 D 16-bit values, the fp8 operand rows -- are addressed with 32-bit offsets)
+        return min(max(int(requested), default), max(default, MAX_ENGINE_BATCH_ROWS // int(tokens)))
     if requested:
         return max(1, int(requested))
     return default
