@@ -57,7 +57,7 @@ def _whole_volume_checks(gpu, vits8, oracle, vol, windows, tol=TOL):
     feats = vt.feature_volume(None, model, 64, 'all', 32, dvol=dvol)
     assert feats.shape == (D, 64, 64, 64) and feats.dtype == torch.float16
     assert bool(torch.isfinite(feats).all())
-    for eb in (31, vt.extract.DEFAULT_ENGINE_BATCH):                        # other batchings of the same slices
+    for eb in (31, vt.extract.engine_batch_for(4097, D)):                   # other batchings of the same slices (the default: 512 / 256)
         again = vt.feature_volume(None, model, 64, 'all', eb, dvol=dvol)
         assert torch.equal(feats, again), f'bits depend on the engine batch ({eb} vs 32)'
         del again

@@ -449,6 +449,19 @@ def test_fos128_long_sequence(gpu):
     assert torch.equal(many[33].cpu(), one[0])                            # bits do not depend on the batching
 
 
+def test_engine_refuses_a_batch_beyond_its_32_bit_offsets(gpu):
+    """A call whose widest buffer would pass 2^32 elements (ViT-B/8 at N = 4097: more than 349 slices) is refused with
+    VITTF_ERR_INVALID_ARG instead of being computed with wrapped offsets (found when the default batch of the ViT-S path went
+    to 512: an explicit engine_batch=512 at D = 768 returned wrong features without an error)."""
+    sd = vt.synthetic_state_dict((768, 1, 12, 8), 3)
+    model = vt.HipViT(sd, (768, 1, 12, 8), 'fp16', device=gpu)
+    vol = torch.zeros((512, 512, 400))
+    vol[0, 0, 0] = 1.0
+    dv = vt.DeviceVolume(vol, gpu)
+    with pytest.raises(vt.VittfError):
+        vt.k_slices(model, dv, 'z', (512, 512, 400), 0, 400, engine_batch=400)
+
+
 def test_optional_paths_agree_with_default(gpu):
     """The engine's alternative paths -- the GEMM launches instead of the block-tail / activation-stationary kernels, every
     LayerNorm as its own launch, un-scaled q with the online-maximum attention kernel (vittf_vit_config.flags) -- compute the

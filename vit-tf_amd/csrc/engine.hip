@@ -115,6 +115,9 @@ extern "C" int vittf_vit_k_features(const vittf_vit_config* cfg, const vittf_vit
   if (view->out_rows % p || view->out_cols % p) return VITTF_ERR_INVALID_ARG;
   const int tokens = (view->out_rows / p) * (view->out_cols / p) + 1;
   const int64_t rows = (int64_t)batch * tokens;
+  // the GEMM kernels index a call's widest buffer -- [rows][4 D] 16-bit hidden values, [rows][3 D] on the block-tail path -- with
+  // 32-bit element offsets: a batch beyond that is refused, not computed wrong (ViT-B/8 at N = 4097: 349 slices)
+  if (rows * (int64_t)((d == 384 && w->tail_packed) ? 3 * d : 4 * d) > 0xffffffffll) return VITTF_ERR_INVALID_ARG;
   const WsLayout lay = ws_layout(d, rows, cfg->attention_fp8 ? vittf_attention_fp8_workspace_bytes(batch, tokens, cfg->heads) : 0);
   if (ws_bytes < lay.total) return VITTF_ERR_WORKSPACE;
   if (((uintptr_t)ws & 255) != 0) return VITTF_ERR_INVALID_ARG;
