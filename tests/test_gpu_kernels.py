@@ -485,6 +485,46 @@ def test_patch_embed_matches_prepare_tokens(gpu, axis, shape, im_sz):
     assert torch.allclose(got, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('axis', ['z', 'y', 'x'])
+@pytest.mark.parametrize('shape,im_sz', [((24, 16, 32), (24, 16, 32)), ((20, 12, 28), (16, 8, 16)), ((10, 10, 10), (32, 32, 32)),
+                                         ((40, 136, 136), (136, 136, 136))])       # 290 tokens x 40 slices: 45 full tiles + a ragged one
+def test_patch_embed_vits8_on_the_matrix_cores(gpu, axis, shape, im_sz):
+    """The ViT-S/8 form of the same step (D = 384, P = 8: patch_embed_mfma_kernel, fp16 head + tail operands on the matrix
+    cores): against the oracle's prepare_tokens at the generic kernel's tolerance, and against the fp64 sum over the same fp32
+    pixels and weights at 2e-6 of a row's largest value (the split drops lo x lo and rounds each tail to fp16: 2^-21)."""
+    arch = (384, 1, 6, 8)
+    sd = vt.synthetic_state_dict(arch, 3)
+    oracle = dino_vit.build_vit(arch, sd)
+    vol = (torch.rand(shape, generator=gen(11)) * 300 - 100).half().float()
+    imgs = ofv.normalized_slices(vol, axis)
+    rows, cols = ofv.axis_image_size(im_sz, axis)
+    with torch.no_grad():
+        x_in = F.interpolate(imgs, size=(rows, cols), mode='nearest')
+        ref = oracle.prepare_tokens(x_in)
+        ref64 = oracle.double().prepare_tokens(x_in.double())
+    model = vt.HipViT(sd, arch, 'fp16')
+    dvol = vt.DeviceVolume(vol, gpu)
+    view = dvol.view(axis, im_sz)
+    pos, _, _ = model.pos_for(rows, cols)
+    n_slices = imgs.shape[0]
+    out = torch.full((n_slices + 1, ref.shape[1], 384), 7.0, device=gpu)
+    _lib.check(model.lib.vittf_patch_embed(C.byref(model.cfg), C.byref(model.weights), C.byref(pos), C.byref(view), 0,
+                                           n_slices, _lib.ptr(out), _lib.stream_ptr()))
+    got = out.cpu()
+    assert (got[n_slices:] == 7.0).all(), 'wrote past the last row'
+    got = got[:n_slices]
+    assert got.shape == ref.shape
+    assert torch.allclose(got, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    err = (got.double() - ref64).abs().amax(dim=-1)
+    assert bool((err <= 2e-6 * ref64.abs().amax(dim=-1).clamp_min(1.0)).all()), float(err.max())
+    # a second call over a sub-range of the slices writes the same bits (rows are independent of the tiling)
+    if n_slices > 3:
+        part = torch.zeros(2, ref.shape[1], 384, device=gpu)
+        _lib.check(model.lib.vittf_patch_embed(C.byref(model.cfg), C.byref(model.weights), C.byref(pos), C.byref(view), 1, 2,
+                                               _lib.ptr(part), _lib.stream_ptr()))
+        assert torch.equal(part.cpu(), got[1:3])
+
+
 # ------------------------------------------------------------------------------------------ pooling / axis sum
 @pytest.mark.parametrize('axis', ['z', 'y', 'x'])
 @pytest.mark.parametrize('S,n_out,f0,f1', [(32, 4, 3, 2), (10, 4, 4, 4), (7, 7, 2, 70), (130, 130, 1, 3), (16, 1, 5, 5)])

@@ -5,8 +5,8 @@
 //   norm_minmax (infer.py:32-34), the 3-channel expand + ImageNet normalize (infer.py:154-155),
 //   F.interpolate(..., mode='nearest') (infer.py:177) and PatchEmbed + prepare_tokens of the upstream ViT.
 // The three input channels are the same grey value, so the conv is folded on the host to ONE input channel
-// (P*P taps) plus a bias; the arithmetic here is exact fp32 (VALU FMAs) -- the front end is < 0.1 % of the
-// path's FLOPs and the precision of the first layer is worth more than its speed.
+// (P*P taps) plus a bias; the arithmetic is fp32 VALU FMAs in the generic kernel and, for ViT-S/8, split-fp16 products on
+// the matrix cores that stay within 1e-6 of it (patch_embed_mfma_kernel): the precision of the first layer is kept.
 #include "vittf_common.h"
 
 namespace {
@@ -127,6 +127,121 @@ __global__ __launch_bounds__(384) void patch_embed_kernel(vittf_slice_view view,
   }
 }
 
+// ---------------------------------------------------------------- patch embed on the matrix cores (D = 384, P = 8)
+// The same sum, x[token][d] = sum_k px[token][k] w[k][d] + bias[d] + pos[token][d], with both operands split into an fp16 head
+// and an fp16 tail (v = hi + lo to 2^-22 |v|; the products of fp16 values are exact in the fp32 accumulator) and three
+// MFMAs per 16-wide k step: hi.hi + lo.hi + hi.lo -- 1.5 TFLOP per 512-slice launch instead of 0.1 TFLOP of fp32 FMAs at a
+// fifth of the VALU's rate (1.67 ms per 256 slices, 1.5 % of the step).  Within 1e-6 of the fp32 chain relative to a row's
+// largest value; per-row arithmetic, so the bits do not depend on the batching.
+//   * persistent workgroups of 8 waves; the weights (12 output tiles x 4 k steps x {hi, lo} fragments of 1 KB = 96 KB)
+//     are split once per workgroup into LDS in fragment order (lane-linear 16-byte reads);
+//   * a wave owns 32 consecutive token rows: lane (row, half h) gathers the pixels of patch rows h, 2 + h, 4 + h, 6 + h --
+//     exactly the B operand's k = 16 s + 8 h + e -- with sample_kernel's nearest-resize arithmetic, so no pixel goes through LDS;
+//   * two passes of 6 output tiles (96 accumulator registers); epilogue from the accumulator layout: lane owns row j, columns
+//     32 ot + 8 g + 4 h + {0 .. 3}: + bias + position embedding as 16-byte loads, 16-byte stores (48 of each per 32 rows: far
+//     below this kernel's budget); the CLS row of a slice takes cls_token + pos[0].
+constexpr int PEM_D = 384, PEM_K = 64, PEM_FRAGS = (PEM_D / 32) * (PEM_K / 16) * 2;
+__global__ __launch_bounds__(512, 1) void patch_embed_mfma_kernel(vittf_slice_view view, int slice0, int batch,
+                                                                  const float* __restrict__ w_t, const float* __restrict__ bias,
+                                                                  const float* __restrict__ cls_pos0,
+                                                                  const float* __restrict__ patch_pos,
+                                                                  float* __restrict__ tokens_out, int f0, int f1) {
+  __shared__ __attribute__((aligned(16))) unsigned short wlds[PEM_FRAGS * 512];      // 96 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  // fragment (ot, s, hl): lane (i = l31, half hh) holds w[16 s + 8 hh + e][32 ot + i], e = 0 .. 7
+  for (int it = tid; it < (PEM_FRAGS / 2) * 64; it += 512) {
+    const int fr = it >> 6, ln = it & 63;
+    const int ot = fr >> 2, s = fr & 3;
+    const int i = ln & 31, hh = ln >> 5;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = w_t[(int64_t)(16 * s + 8 * hh + e) * PEM_D + 32 * ot + i];
+      const unsigned short hi = f32_to_f16bits(v);
+      const unsigned short lo = f32_to_f16bits(v - f16bits_to_f32(hi));
+      wlds[((fr * 2 + 0) * 64 + ln) * 8 + e] = hi;
+      wlds[((fr * 2 + 1) * 64 + ln) * 8 + e] = lo;
+    }
+  }
+  __syncthreads();
+  const int npatch = f0 * f1, tokens = npatch + 1;
+  const int64_t rows = (int64_t)batch * tokens;
+  const float lo_v = view.minmax[0], range = view.minmax[1] - view.minmax[0];
+  const float sr = (float)view.in_rows / (float)view.out_rows;
+  const float sc = (float)view.in_cols / (float)view.out_cols;
+  const int64_t ntile = (rows + 255) / 256;
+  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int64_t r = tile * 256 + wave * 32 + l31;
+    const bool valid = r < rows;
+    const int b = valid ? (int)(r / tokens) : 0;
+    const int t = valid ? (int)(r - (int64_t)b * tokens) : 0;
+    const bool patch = valid && t > 0;
+    const int p = patch ? t - 1 : 0;
+    const int py = p / f1, pxx = p - py * f1;
+    const float* slice = view.vol + (int64_t)(slice0 + b) * view.stride_slice;
+    // the B operands: k step s = patch row 2 s + h, 8 columns
+    s16x8_t bh[4], bl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int iy = py * 8 + 2 * s + h;
+      int ry = (int)floorf((float)iy * sr);
+      ry = ry < view.in_rows - 1 ? ry : view.in_rows - 1;
+      unsigned short hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ix = pxx * 8 + e;
+        int cx = (int)floorf((float)ix * sc);
+        cx = cx < view.in_cols - 1 ? cx : view.in_cols - 1;
+        float v = 0.f;
+        if (patch) v = (slice[(int64_t)ry * view.stride_row + (int64_t)cx * view.stride_col] - lo_v) / range;
+        hi[e] = f32_to_f16bits(v);
+        lo[e] = f32_to_f16bits(v - f16bits_to_f32(hi[e]));
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { bh[s][e] = (short)hi[e]; bl[s][e] = (short)lo[e]; }
+    }
+    float* orow = tokens_out + r * PEM_D;
+    const float* prow = patch_pos + (int64_t)p * PEM_D;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      f32x16_t acc[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int fr = (6 * pass + j) * 4 + s;
+          const s16x8_t ah = *reinterpret_cast<const s16x8_t*>(&wlds[((fr * 2 + 0) * 64 + lane) * 8]);
+          const s16x8_t al = *reinterpret_cast<const s16x8_t*>(&wlds[((fr * 2 + 1) * 64 + lane) * 8]);
+          acc[j] = mfma32<VITTF_FP16>(ah, bh[s], acc[j]);
+          acc[j] = mfma32<VITTF_FP16>(al, bh[s], acc[j]);
+          acc[j] = mfma32<VITTF_FP16>(ah, bl[s], acc[j]);
+        }
+      if (valid) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c = 32 * (6 * pass + j) + 8 * g + 4 * h;
+            float4 o;
+            if (patch) {
+              const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+              const float4 pv = *reinterpret_cast<const float4*>(prow + c);
+              o.x = acc[j][4 * g + 0] + bv.x + pv.x; o.y = acc[j][4 * g + 1] + bv.y + pv.y;
+              o.z = acc[j][4 * g + 2] + bv.z + pv.z; o.w = acc[j][4 * g + 3] + bv.w + pv.w;
+            } else {
+              o = *reinterpret_cast<const float4*>(cls_pos0 + c);
+            }
+            *reinterpret_cast<float4*>(orow + c) = o;
+          }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t vittf_minmax_workspace_bytes(void) { return 2 * MM_BLOCKS * sizeof(float); }
@@ -157,6 +272,15 @@ extern "C" int vittf_patch_embed(const vittf_vit_config* cfg, const vittf_vit_we
   const int f0 = view->out_rows / p, f1 = view->out_cols / p;
   const int nblk = (f0 * f1 + TP - 1) / TP;
   hipStream_t st = (hipStream_t)stream;
+  if (cfg->embed_dim == PEM_D && p == 8 && (((uintptr_t)w->pe_b | (uintptr_t)pos->cls_plus_pos0 | (uintptr_t)pos->patch_pos | (uintptr_t)tokens_out) & 15) == 0) {
+    // ViT-S/8: the conv on the matrix cores with fp16 head + tail operands (see patch_embed_mfma_kernel)
+    const int cus = vittf_current_cus();
+    if (cus <= 0) return VITTF_ERR_NO_DEVICE;
+    const int64_t ntile = ((int64_t)batch * (f0 * f1 + 1) + 255) / 256;
+    hipLaunchKernelGGL(patch_embed_mfma_kernel, dim3((unsigned)(ntile < cus ? ntile : cus)), dim3(512), 0, st, *view, slice0, batch,
+                       w->pe_w_t, w->pe_b, pos->cls_plus_pos0, pos->patch_pos, tokens_out, f0, f1);
+    return vittf_check_launch();
+  }
   const int threads = cfg->embed_dim % 384 == 0 ? 384 : 256;   // one feature per thread in a single pass for D = 384 / 768
   if (p == 8) {
     hipLaunchKernelGGL((patch_embed_kernel<8>), dim3(nblk, batch), dim3(threads), 0, st, *view, slice0, w->pe_w_t, w->pe_b,
